@@ -1,0 +1,51 @@
+"""Helpers shared by the test modules."""
+import os
+
+import numpy as np
+
+from raytracing_amd import scenes
+
+FLT_MAX = np.finfo(np.float32).max
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def obj_scene(name):
+    return scenes.load_obj(os.path.join(GOLDEN, "render-data", name))
+
+
+def original_ids(hits, tri_after_build):
+    """Map hit refs of a tracer that permuted the triangle list (flat layout, naive_bvh) back to the
+    ids of the list the scene was created with. Works for scenes whose triangles own their vertices
+    (vertex id // 3 == original triangle id), which every scene in raytracing_amd.scenes does."""
+    ref = hits["ref"].astype(np.int64)
+    valid = hits["t"] != FLT_MAX
+    out = np.zeros_like(ref)
+    out[valid] = tri_after_build[ref[valid], 0] // 3
+    return out
+
+
+def rays_toward_scene(pos, n, seed):
+    """Random rays that start outside/inside the scene bounds and aim at random points of it."""
+    rs = np.random.RandomState(seed)
+    lo, hi = pos.min(0), pos.max(0)
+    c, e = (lo + hi) / 2, np.maximum(hi - lo, 1e-3)
+    o = c + rs.uniform(-1.5, 1.5, size=(n, 3)) * e
+    target = lo + rs.uniform(0, 1, size=(n, 3)) * (hi - lo)
+    d = target - o
+    d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-20)
+    rays = np.empty((n, 8), np.float32)
+    rays[:, 0:3], rays[:, 3:6], rays[:, 6], rays[:, 7] = o, d, 1e-4, FLT_MAX
+    return rays
+
+
+def assert_hits_equal(got, want, what=""):
+    """Bit-exact comparison of hit buffers (t, ref always; beta, gamma where there is a hit)."""
+    assert got.shape == want.shape
+    valid = want["t"] != FLT_MAX
+    bad_t = np.flatnonzero(got["t"].view(np.uint32) != want["t"].view(np.uint32))
+    assert bad_t.size == 0, "%s: %d rays differ in t, first %s" % (what, bad_t.size, bad_t[:5])
+    bad_ref = np.flatnonzero(got["ref"] != want["ref"])
+    assert bad_ref.size == 0, "%s: %d rays differ in ref, first %s" % (what, bad_ref.size, bad_ref[:5])
+    for k in ("beta", "gamma"):
+        bad = np.flatnonzero(got[k][valid].view(np.uint32) != want[k][valid].view(np.uint32))
+        assert bad.size == 0, "%s: %d rays differ in %s" % (what, bad.size, k)
