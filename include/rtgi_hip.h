@@ -1,0 +1,134 @@
+/* rtgi_hip.h -- C ABI of the MI355X ray-traversal backend for the rtgi renderer.
+ *
+ * One handle = one tracer object bound to one GPU.  It plays the role of a
+ * binary_bvh_tracer<layout, esc> (rt/bbvh-base/bvh.h:29-107) behind the ray_tracer /
+ * individual_ray_tracer / wf::batch_ray_tracer interfaces (libgi/rt.h:91-107,
+ * libgi/wavefront-rt.h:10-16): build() on the host, closest_hit / any_hit on the GPU.
+ *
+ * Conventions: every function returns RTGI_OK (0) or a negative RTGI_ERR_* code, never throws and
+ * never aborts; rtgi_hip_last_error() gives the text.  Calls on one handle must be serialised by the
+ * caller (launches share the handle's traversal scratch); different handles may be used from
+ * different host threads.  Pointers named d_* are device pointers on the handle's GPU, all others are
+ * host pointers.  File:line citations are relative to the reference tree
+ * "Assignment 3/rtgi-2021-a03-ref/".
+ */
+#ifndef RTGI_HIP_H
+#define RTGI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rtgi_hip_tracer rtgi_hip_tracer;
+
+/* struct ray, libgi/rt.h:20-27, without the derived member id = 1/d (the kernels recompute it with the
+ * same IEEE division the constructor uses). 32 bytes. */
+typedef struct rtgi_ray {
+	float o[3];
+	float d[3];
+	float t_min; /* reference default 1e-4f */
+	float t_max; /* reference default FLT_MAX; length_exclusive(len) stores len - 1e-4f */
+} rtgi_ray;
+
+/* struct triangle_intersection, libgi/rt.h:40-62. t == FLT_MAX means "no hit" (then ref, beta, gamma
+ * are 0). 16 bytes. */
+typedef struct rtgi_hit {
+	float t, beta, gamma;
+	uint32_t ref;
+} rtgi_hit;
+
+/* binary_bvh_tracer::node, rt/bbvh-base/bvh.h:39-47: box = min.xyz, max.xyz; a leaf has link_r < 0,
+ * then -link_l is the first slot in the triangle index and -link_r the triangle count. 56 bytes. */
+typedef struct rtgi_node56 {
+	float box_l[6];
+	float box_r[6];
+	int32_t link_l, link_r;
+} rtgi_node56;
+
+enum {
+	RTGI_OK = 0,
+	RTGI_ERR_INVALID = -1,   /* bad argument, malformed scene or tree */
+	RTGI_ERR_DEVICE = -2,    /* a HIP call failed */
+	RTGI_ERR_NOT_BUILT = -3, /* traversal before build()/upload */
+	RTGI_ERR_NOMEM = -4,
+	RTGI_ERR_SYNTAX = -5     /* interprete(): command recognised, arguments malformed */
+};
+enum { RTGI_LAYOUT_FLAT = 0, RTGI_LAYOUT_INDEXED = 1 }; /* bvh.h:29 bbvh_triangle_layout */
+enum { RTGI_SPLIT_OM = 0, RTGI_SPLIT_SM = 1, RTGI_SPLIT_SAH = 2 }; /* bvh.h:62 binary_split_type */
+
+/* Number of usable GPUs (0 if none; never fails). */
+int rtgi_hip_device_count(void);
+
+/* "raytracer bbvh [indexed] [esc]", driver/interaction.cpp:177-203: creates the tracer the registry
+ * would create with `new binary_bvh_tracer<layout, esc>`. flat + esc is refused like the registry does
+ * (interaction.cpp:195-196). device = -1 gives a host-only handle: it builds, takes over and reads back
+ * trees but every traversal call fails with RTGI_ERR_DEVICE. Returns NULL on failure. */
+rtgi_hip_tracer *rtgi_hip_create(int device, int layout, int esc);
+
+/* ~ray_tracer(), libgi/rt.h:97. Frees all host and device memory of the handle. */
+void rtgi_hip_destroy(rtgi_hip_tracer *h);
+
+/* ray_tracer::interprete(command, in), bvh2.cpp:503-555: `args` is the rest of the command line.
+ * Handles "bvh om | sm | sah N | triangles single | triangles multiple N | statistics | export D file".
+ * Returns 1 if the command was consumed, 0 if it is not for this tracer, RTGI_ERR_SYNTAX if it was
+ * recognised but malformed (the reference prints an error and still reports "consumed"). */
+int rtgi_hip_interprete(rtgi_hip_tracer *h, const char *command, const char *args);
+
+/* ray_tracer::build(scene*), bvh2.cpp:27-63: builds the tree from scene->vertices / scene->triangles
+ * (libgi/scene.h:80-81) with the split scheme selected through interprete(), then flattens it for the
+ * GPU and uploads it. `vertices` points at the first position (3 floats) of records vertex_stride bytes
+ * apart (sizeof(vertex) = 32, rt.h:29-33); `triangles` at the first of three uint32 vertex ids of
+ * records tri_stride bytes apart (sizeof(triangle) = 16, rt.h:35-38). Non-finite positions and
+ * out-of-range vertex ids are refused. The scene arrays are not modified: for the flat layout, apply
+ * rtgi_hip_get_triangle_order() to scene->triangles afterwards (commit_shuffled_triangles,
+ * bvh2.cpp:172-180). */
+int rtgi_hip_build(rtgi_hip_tracer *h, const void *vertices, size_t vertex_stride, uint32_t n_vertices,
+                   const void *triangles, size_t tri_stride, uint32_t n_triangles);
+
+/* Takes a tree built elsewhere (e.g. by the reference's own builder) verbatim: `nodes`/`root` as in
+ * binary_bvh_tracer::nodes/root (bvh.h:59-68); `index` = the leaf-order triangle list, i.e.
+ * binary_bvh_tracer::index for the indexed layout, NULL (identity over the already permuted
+ * scene->triangles) for the flat layout. The tree is checked (links in range, every node reached once,
+ * leaf ranges inside the index) before anything is uploaded. */
+int rtgi_hip_upload_bvh(rtgi_hip_tracer *h, const rtgi_node56 *nodes, uint32_t n_nodes, uint32_t root,
+                        const uint32_t *index, uint32_t n_index, const void *vertices, size_t vertex_stride,
+                        uint32_t n_vertices, const void *triangles, size_t tri_stride, uint32_t n_triangles);
+
+/* Read-back of the host tree in the reference's own format (bvh.h:59-68), e.g. for `bvh export`. */
+uint32_t rtgi_hip_num_nodes(const rtgi_hip_tracer *h);
+uint32_t rtgi_hip_num_index(const rtgi_hip_tracer *h); /* leaf-order slots (> n_triangles with esc) */
+uint32_t rtgi_hip_root(const rtgi_hip_tracer *h);
+uint32_t rtgi_hip_depth(const rtgi_hip_tracer *h);     /* deepest leaf, root = 0 */
+int rtgi_hip_get_nodes(const rtgi_hip_tracer *h, rtgi_node56 *out);
+/* Leaf-order list of ORIGINAL triangle ids (index[] of the indexed layout; for the flat layout the
+ * permutation new_tris[i] = old_tris[out[i]] of bvh2.cpp:176-179). */
+int rtgi_hip_get_triangle_order(const rtgi_hip_tracer *h, uint32_t *out);
+
+/* wf::batch_ray_tracer::compute_closest_hit(), libgi/wavefront-rt.h:67-73, over n rays in host memory:
+ * hits[i] = closest_hit(rays[i]) (bvh2.cpp:415-463). ref is the id the reference would return: an
+ * index into the permuted triangle list for the flat layout, an original id for the indexed one.
+ * Copies rays to the GPU, traces, copies hits back; synchronous. */
+int rtgi_hip_closest_hit(rtgi_hip_tracer *h, const rtgi_ray *rays, uint32_t n, rtgi_hit *hits);
+
+/* compute_any_hit(), wavefront-rt.h:74-80 / bvh2.cpp:465-501: occluded[i] = any_hit(rays[i]) as 0/1. */
+int rtgi_hip_any_hit(rtgi_hip_tracer *h, const rtgi_ray *rays, uint32_t n, uint8_t *occluded);
+
+/* The same two operations on rays that already live on the GPU (the wavefront pipeline's form):
+ * asynchronous on `stream` (a hipStream_t, NULL = default stream). d_counts, if not NULL, receives two
+ * uint32 per ray: inner nodes popped and triangles tested (what a COUNT_HITS build, bvh.h:10, counts,
+ * minus the leaf-node pops). */
+int rtgi_hip_closest_hit_device(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint32_t n, rtgi_hit *d_hits,
+                                uint32_t *d_counts, void *stream);
+int rtgi_hip_any_hit_device(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint32_t n, uint8_t *d_occluded,
+                            uint32_t *d_counts, void *stream);
+
+/* Text of the last error on this handle (h may be NULL: last error of a failed create). */
+const char *rtgi_hip_last_error(const rtgi_hip_tracer *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTGI_HIP_H */

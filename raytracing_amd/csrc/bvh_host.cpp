@@ -1,0 +1,502 @@
+// bvh_host.cpp -- BVH construction (object median / spatial median / binned SAH, optional early split
+// clipping) producing the same tree as rt/bbvh-base/bvh2.cpp of the reference, and flattening for the GPU.
+//
+// The tree must be the reference's tree bit for bit: which boxes a ray enters decides which triangle wins
+// a near-tie, so every comparison and every rounding step below keeps the reference's form (noted per
+// function as file:line of "Assignment 3/rtgi-2021-a03-ref/"). Build with -ffp-contract=off.
+#include "bvh_host.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+namespace rtgi {
+namespace {
+
+struct F3 {
+	float v[3];
+	float operator[](int i) const { return v[i]; }
+	float &operator[](int i) { return v[i]; }
+};
+
+// aabb of libgi/intersect.h:5-16; grow() keeps glm's operand order: min = (min < p) ? min : p,
+// max = (p < max) ? max : p.
+struct Bounds {
+	F3 lo{{FLT_MAX, FLT_MAX, FLT_MAX}}, hi{{-FLT_MAX, -FLT_MAX, -FLT_MAX}};
+	void add(const F3 &p) {
+		for (int k = 0; k < 3; ++k) {
+			lo[k] = (lo[k] < p[k]) ? lo[k] : p[k];
+			hi[k] = (p[k] < hi[k]) ? hi[k] : p[k];
+		}
+	}
+	void add(const Bounds &b) {
+		for (int k = 0; k < 3; ++k) {
+			lo[k] = (lo[k] < b.lo[k]) ? lo[k] : b.lo[k];
+			hi[k] = (b.hi[k] < hi[k]) ? hi[k] : b.hi[k];
+		}
+	}
+	float surface() const {  // bvh2.cpp:315-318
+		float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+		return 2 * (ex * ey + ex * ez + ey * ez);
+	}
+	// axis choice of bvh2.cpp:212-222: x wins ties over y, y over z
+	int longest_axis(F3 &ext) const {
+		for (int k = 0; k < 3; ++k) ext[k] = hi[k] - lo[k];
+		float m = (ext[1] < ext[2]) ? ext[2] : ext[1];
+		float largest = (ext[0] < m) ? m : ext[0];
+		return largest == ext[0] ? 0 : (largest == ext[1] ? 1 : 2);
+	}
+};
+
+F3 load_pos(const SceneView &s, uint32_t v) {
+	const float *p = s.pos(v);
+	return F3{{p[0], p[1], p[2]}};
+}
+
+void store_box(float *dst6, const Bounds &b) {
+	for (int k = 0; k < 3; ++k) {
+		dst6[k] = b.lo[k];
+		dst6[3 + k] = b.hi[k];
+	}
+}
+
+class Builder {
+public:
+	Builder(const BuildConfig &cfg, const SceneView &scene, HostTree &out) : cfg(cfg), scene(scene), out(out) {}
+
+	bool run(std::string &err) {
+		const uint32_t n = scene.n_triangles;
+		boxes.resize(n);
+		owner.resize(n);
+		slots.resize(n);
+		for (uint32_t i = 0; i < n; ++i) {  // bvh2.cpp:35-43
+			const uint32_t *t = scene.tri(i);
+			boxes[i].add(load_pos(scene, t[0]));
+			boxes[i].add(load_pos(scene, t[1]));
+			boxes[i].add(load_pos(scene, t[2]));
+			owner[i] = i;
+			slots[i] = i;
+		}
+		if (cfg.esc && !clip_large_triangles(err)) return false;
+		centre.resize(boxes.size());
+		for (size_t i = 0; i < boxes.size(); ++i)  // prim::center(), bvh.h:52
+			for (int k = 0; k < 3; ++k) centre[i][k] = (boxes[i].lo[k] + boxes[i].hi[k]) * 0.5f;
+
+		out.nodes.clear();
+		out.nodes.reserve(2 * boxes.size());
+		out.root = split_range(0, (uint32_t)boxes.size(), 0);
+		out.depth = deepest;
+
+		// commit_shuffled_triangles, bvh2.cpp:172-190: slot -> original triangle id
+		out.order.resize(slots.size());
+		for (size_t s = 0; s < slots.size(); ++s) out.order[s] = owner[slots[s]];
+		return true;
+	}
+
+private:
+	const BuildConfig &cfg;
+	const SceneView &scene;
+	HostTree &out;
+	std::vector<Bounds> boxes;    // one per primitive box (more than triangles after clipping)
+	std::vector<uint32_t> owner;  // primitive box -> triangle
+	std::vector<F3> centre;
+	std::vector<uint32_t> slots;  // the 'index' array the reference sorts
+	uint32_t deepest = 0;
+
+	uint32_t new_node() {
+		out.nodes.emplace_back();
+		rtgi_node56 &n = out.nodes.back();
+		store_box(n.box_l, Bounds());
+		store_box(n.box_r, Bounds());
+		n.link_l = n.link_r = 0;
+		return (uint32_t)out.nodes.size() - 1;
+	}
+	uint32_t leaf(uint32_t start, uint32_t end, uint32_t depth) {
+		uint32_t id = new_node();
+		out.nodes[id].link_l = -(int32_t)start;
+		out.nodes[id].link_r = -(int32_t)(end - start);
+		if (depth > deepest) deepest = depth;
+		return id;
+	}
+	Bounds range_bounds(uint32_t start, uint32_t end) const {
+		Bounds b;
+		for (uint32_t i = start; i < end; ++i) b.add(boxes[slots[i]]);
+		return b;
+	}
+	void sort_by_centre(uint32_t start, uint32_t end, int axis) {
+		std::sort(slots.data() + start, slots.data() + end,
+		          [this, axis](uint32_t a, uint32_t b) { return centre[a][axis] < centre[b][axis]; });
+	}
+	// Two-pointer partition of bvh2.cpp:265-277 / :338-353. The slot on which the pointers meet is
+	// left unexamined on the right-hand side, exactly as there.
+	uint32_t partition_at(uint32_t start, uint32_t end, int axis, float plane) {
+		uint32_t mid = start, l = start, r = end - 1;
+		while (l < r) {
+			while (centre[slots[l]][axis] <= plane && l < r) {
+				++l;
+				++mid;
+			}
+			while (centre[slots[r]][axis] > plane && l < r) --r;
+			if (centre[slots[l]][axis] > centre[slots[r]][axis] && l < r) std::swap(slots[l], slots[r]);
+		}
+		return mid;
+	}
+
+	uint32_t split_range(uint32_t start, uint32_t end, uint32_t depth) {
+		if (end - start <= (uint32_t)cfg.max_tris) return leaf(start, end, depth);
+		Bounds all = range_bounds(start, end);
+		F3 ext;
+		int axis = all.longest_axis(ext);
+		uint32_t mid = start;
+		Bounds left, right;
+		bool have_child_boxes = false;
+
+		if (cfg.split == RTGI_SPLIT_OM) {  // bvh2.cpp:192-235
+			sort_by_centre(start, end, axis);
+			mid = start + (end - start) / 2;
+		} else if (cfg.split == RTGI_SPLIT_SM) {  // bvh2.cpp:237-298
+			float plane = all.lo[axis] + (all.hi[axis] - all.lo[axis]) * 0.5f;
+			mid = partition_at(start, end, axis, plane);
+			if (mid == start || mid == end - 1) {
+				sort_by_centre(start, end, axis);
+				mid = start + (end - start) / 2;
+			}
+		} else {  // bvh2.cpp:300-413
+			float cost_l = FLT_MAX, cost_r = FLT_MAX;
+			bool median_fallback_left = true;
+			int n_planes = cfg.planes;
+			if ((int)(end - start) < n_planes) n_planes = (int)(end - start);
+			const float whole = all.surface();
+			for (int i = 0; i < n_planes; ++i) {
+				float plane = all.lo[axis] + (i + 1) * (ext[axis] / (n_planes + 1));
+				uint32_t m = partition_at(start, end, axis, plane);
+				if (m == start || m == end - 1) {
+					if (!median_fallback_left) continue;
+					sort_by_centre(start, end, axis);
+					m = start + (end - start) / 2;
+					median_fallback_left = false;
+				}
+				Bounds bl = range_bounds(start, m), br = range_bounds(m, end);
+				float cl = (bl.surface() / whole) * (m - start);
+				float cr = (br.surface() / whole) * (end - m);
+				if (cl + cr < cost_l + cost_r) {
+					left = bl;
+					right = br;
+					cost_l = cl;
+					cost_r = cr;
+					mid = m;
+				}
+			}
+			have_child_boxes = true;
+			if (cfg.max_tris > 1)  // K_T = K_I = 1, bvh2.cpp:13-14 and :395-403
+				if ((float)(end - start) < (1 + 1 * (cost_l + cost_r)) && (end - start) <= (uint32_t)cfg.max_tris)
+					return leaf(start, end, depth);
+		}
+
+		uint32_t id = new_node();
+		uint32_t l = split_range(start, mid, depth + 1);
+		uint32_t r = split_range(mid, end, depth + 1);
+		if (!have_child_boxes) {
+			left = range_bounds(start, mid);
+			right = range_bounds(mid, end);
+		}
+		rtgi_node56 &n = out.nodes[id];
+		n.link_l = (int32_t)l;
+		n.link_r = (int32_t)r;
+		store_box(n.box_l, left);
+		store_box(n.box_r, right);
+		return id;
+	}
+
+	// split(), bvh2.cpp:65-126: cut a polygon at the middle of the longest axis of its box until every
+	// piece's box surface is at most `limit`; collects the piece boxes.
+	bool cut_polygon(const std::vector<F3> &poly, float limit, std::vector<Bounds> &pieces, int level) {
+		Bounds b;
+		for (const F3 &p : poly) b.add(p);
+		if (b.surface() <= limit) {
+			pieces.push_back(b);
+			return true;
+		}
+		if (level > 64 || poly.empty()) return false;
+		F3 ext;
+		int axis = b.longest_axis(ext);
+		const float mid = (b.hi[axis] + b.lo[axis]) * 0.5f;
+		const int n = (int)poly.size();
+		bool prev_left = poly[0][axis] < mid;
+		int first = -1, second = -1;
+		for (int i = 0; i < n; ++i) {
+			bool is_left = poly[i][axis] < mid;
+			if (is_left != prev_left) {
+				if (first == -1)
+					first = i - 1;
+				else
+					second = i - 1;
+			}
+			prev_left = is_left;
+		}
+		if (second == -1) second = n - 1;
+		if (first == -1) return false;  // bvh2.cpp:95 asserts
+		auto crossing = [&](int a) {
+			int nb = a + 1 < n ? a + 1 : 0;
+			float w = (mid - poly[a][axis]) / (poly[nb][axis] - poly[a][axis]);
+			F3 p;
+			for (int k = 0; k < 3; ++k) p[k] = poly[a][k] + (poly[nb][k] - poly[a][k]) * w;
+			return p;
+		};
+		const F3 c1 = crossing(first), c2 = crossing(second);
+		std::vector<F3> one(poly.begin(), poly.begin() + first + 1), two;
+		one.push_back(c1);
+		two.push_back(c1);
+		two.insert(two.end(), poly.begin() + first + 1, poly.begin() + second + 1);
+		two.push_back(c2);
+		one.push_back(c2);
+		one.insert(one.end(), poly.begin() + second + 1, poly.end());
+		auto same = [](const F3 &p, const F3 &q) { return p[0] == q[0] && p[1] == q[1] && p[2] == q[2]; };
+		one.erase(std::unique(one.begin(), one.end(), same), one.end());
+		two.erase(std::unique(two.begin(), two.end(), same), two.end());
+		return cut_polygon(one, limit, pieces, level + 1) && cut_polygon(two, limit, pieces, level + 1);
+	}
+
+	// early_split_clipping, bvh2.cpp:128-170: triangles whose box is larger than the 90th percentile
+	// are represented by several smaller boxes.
+	bool clip_large_triangles(std::string &err) {
+		std::vector<float> area(boxes.size());
+		for (size_t i = 0; i < boxes.size(); ++i) area[i] = boxes[i].surface();
+		std::sort(area.begin(), area.end());
+		const float limit = area[9 * area.size() / 10];
+		const uint32_t n = (uint32_t)boxes.size();
+		for (uint32_t i = 0; i < n; ++i) {
+			const uint32_t *t = scene.tri(i);
+			std::vector<F3> poly{load_pos(scene, t[0]), load_pos(scene, t[1]), load_pos(scene, t[2])};
+			std::vector<Bounds> pieces;
+			if (!cut_polygon(poly, limit, pieces, 0)) {
+				err = "early split clipping: triangle " + std::to_string(i) + " cannot be split (degenerate)";
+				return false;
+			}
+			boxes[i] = pieces[0];
+			for (size_t j = 1; j < pieces.size(); ++j) {
+				boxes.push_back(pieces[j]);
+				owner.push_back(i);
+				slots.push_back((uint32_t)boxes.size() - 1);
+			}
+		}
+		return true;
+	}
+};
+
+}  // namespace
+
+bool check_scene(const SceneView &s, std::string &err) {
+	if (!s.vertices || !s.triangles || s.n_vertices == 0 || s.n_triangles == 0) {
+		err = "there is no scene data to work with";
+		return false;
+	}
+	if (s.vertex_stride < 12 || s.tri_stride < 12 || s.vertex_stride % 4 || s.tri_stride % 4) {
+		err = "vertex/triangle stride must be a multiple of 4 and at least 12 bytes";
+		return false;
+	}
+	if (s.n_triangles > 0x3fffffffu) {
+		err = "too many triangles";
+		return false;
+	}
+	for (uint32_t v = 0; v < s.n_vertices; ++v) {
+		const float *p = s.pos(v);
+		if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) {
+			err = "vertex " + std::to_string(v) + " has a non-finite position";
+			return false;
+		}
+	}
+	for (uint32_t t = 0; t < s.n_triangles; ++t) {
+		const uint32_t *i = s.tri(t);
+		if (i[0] >= s.n_vertices || i[1] >= s.n_vertices || i[2] >= s.n_vertices) {
+			err = "triangle " + std::to_string(t) + " references a vertex out of range";
+			return false;
+		}
+	}
+	return true;
+}
+
+bool build_tree(const BuildConfig &cfg, const SceneView &scene, HostTree &out, std::string &err) {
+	if (!check_scene(scene, err)) return false;
+	if (cfg.layout == RTGI_LAYOUT_FLAT && cfg.esc) {
+		err = "flat layout with early split clipping is technically problematic";
+		return false;
+	}
+	if (cfg.split == RTGI_SPLIT_SAH && cfg.planes <= 0) {
+		err = "\"bvh sah\" needs a positive number of planes";
+		return false;
+	}
+	if (cfg.max_tris < 1) {
+		err = "\"bvh triangles multiple\" needs a positive count";
+		return false;
+	}
+	Builder b(cfg, scene, out);
+	return b.run(err);
+}
+
+bool validate_tree(HostTree &t, uint32_t n_triangles, std::string &err) {
+	const uint32_t n = (uint32_t)t.nodes.size();
+	if (n == 0 || t.root >= n) {
+		err = "tree is empty or the root is out of range";
+		return false;
+	}
+	for (uint32_t id : t.order)
+		if (id >= n_triangles) {
+			err = "triangle index entry out of range";
+			return false;
+		}
+	std::vector<uint8_t> seen(n, 0);
+	std::vector<std::pair<uint32_t, uint32_t>> todo{{t.root, 0u}};
+	t.depth = 0;
+	while (!todo.empty()) {
+		auto [id, d] = todo.back();
+		todo.pop_back();
+		if (seen[id]) {
+			err = "node " + std::to_string(id) + " is reachable twice (not a tree)";
+			return false;
+		}
+		seen[id] = 1;
+		const rtgi_node56 &nd = t.nodes[id];
+		if (nd.link_r >= 0) {
+			if (nd.link_l < 0 || (uint32_t)nd.link_l >= n || (uint32_t)nd.link_r >= n) {
+				err = "node " + std::to_string(id) + " links out of range";
+				return false;
+			}
+			todo.push_back({(uint32_t)nd.link_l, d + 1});
+			todo.push_back({(uint32_t)nd.link_r, d + 1});
+		} else {
+			int64_t off = -(int64_t)nd.link_l, cnt = -(int64_t)nd.link_r;
+			if (off < 0 || cnt < 1 || off + cnt > (int64_t)t.order.size()) {
+				err = "leaf " + std::to_string(id) + " covers slots outside the triangle index";
+				return false;
+			}
+			if (d > t.depth) t.depth = d;
+		}
+	}
+	return true;
+}
+
+void flatten_tree(const HostTree &t, const SceneView &scene, int layout, FlatTree &out) {
+	const uint32_t n = (uint32_t)t.nodes.size();
+	// inner nodes keep their relative (pre-order) position
+	std::vector<int32_t> inner_id(n, -1);
+	uint32_t n_inner = 0;
+	for (uint32_t i = 0; i < n; ++i)
+		if (t.nodes[i].link_r >= 0) inner_id[i] = (int32_t)n_inner++;
+	auto ref_of = [&](uint32_t node) -> int32_t {
+		const rtgi_node56 &nd = t.nodes[node];
+		if (nd.link_r >= 0) return inner_id[node];
+		return ~(int32_t)(-nd.link_l);
+	};
+	out.n_inner = n_inner;
+	out.n_slots = (uint32_t)t.order.size();
+	out.depth = t.depth;
+	out.root_ref = ref_of(t.root);
+	out.nodes.assign((size_t)n_inner * 16, 0.0f);
+	for (uint32_t i = 0; i < n; ++i) {
+		const rtgi_node56 &nd = t.nodes[i];
+		if (nd.link_r < 0) continue;
+		float *g = out.nodes.data() + (size_t)inner_id[i] * 16;
+		int32_t rl = ref_of((uint32_t)nd.link_l), rr = ref_of((uint32_t)nd.link_r);
+		memcpy(g + 0, nd.box_l, 12);
+		memcpy(g + 3, &rl, 4);
+		memcpy(g + 4, nd.box_l + 3, 12);
+		memcpy(g + 7, &rr, 4);
+		memcpy(g + 8, nd.box_r, 12);
+		memcpy(g + 12, nd.box_r + 3, 12);
+	}
+	out.tris.assign((size_t)out.n_slots * 12, 0.0f);
+	for (uint32_t s = 0; s < out.n_slots; ++s) {
+		const uint32_t *v = scene.tri(t.order[s]);
+		const float *A = scene.pos(v[0]), *B = scene.pos(v[1]), *C = scene.pos(v[2]);
+		float *g = out.tris.data() + (size_t)s * 12;
+		// hit ids: position in the permuted list (flat, bvh.h:96-100) or original id (indexed, :102-106)
+		uint32_t id = (layout == RTGI_LAYOUT_FLAT) ? s : t.order[s];
+		for (int k = 0; k < 3; ++k) {
+			g[k] = A[k];
+			g[4 + k] = A[k] - B[k];  // a, b, c of libgi/intersect.h:26-28
+			g[8 + k] = A[k] - C[k];  // d, e, f of :31-33
+		}
+		memcpy(g + 3, &id, 4);
+	}
+	for (uint32_t i = 0; i < n; ++i) {
+		const rtgi_node56 &nd = t.nodes[i];
+		if (nd.link_r >= 0) continue;
+		uint32_t last = (uint32_t)(-nd.link_l) + (uint32_t)(-nd.link_r) - 1;
+		uint32_t one = 1;
+		memcpy(out.tris.data() + (size_t)last * 12 + 7, &one, 4);
+	}
+}
+
+// print_node_stats, bvh2.cpp:599-630 (same figures, including its min/max update order and its
+// median-of-even-count rule)
+std::string tree_statistics(const HostTree &t) {
+	std::vector<int> counts;
+	uint32_t total = 0;
+	int mx = 0, mn = INT32_MAX;
+	for (const rtgi_node56 &nd : t.nodes)
+		if (nd.link_r < 0) {
+			int c = -nd.link_r;
+			counts.push_back(c);
+			if (c < mn)
+				mn = c;
+			else if (c > mx)
+				mx = c;
+			total += c;
+		}
+	std::sort(counts.begin(), counts.end());
+	int median = 0;
+	size_t n = counts.size();
+	if (n % 2 == 1)
+		median = counts[n / 2];
+	else if (n)
+		median = (int)(0.5 * (counts[n / 2] + counts[std::min(n / 2 + 1, n - 1)]));
+	std::ostringstream o;
+	o << "number of leaf nodes: " << n << "\n"
+	  << "minimum triangles per node: " << mn << "\n"
+	  << "maximum triangles per node: " << mx << "\n"
+	  << "average triangles per node: " << (n ? total / n : 0) << "\n"
+	  << "median of triangles per node: " << median << "\n";
+	return o.str();
+}
+
+// export_bvh, bvh2.cpp:557-597: child boxes of the first max_depth levels as OBJ quads
+bool export_tree(const HostTree &t, uint32_t max_depth, const std::string &filename, std::string &err) {
+	std::ofstream f(filename, std::ios::trunc);
+	if (!f) {
+		err = "cannot write " + filename;
+		return false;
+	}
+	uint32_t box_no = 0;
+	auto emit = [&](const float *b, uint32_t depth) {
+		const float *lo = b, *hi = b + 3;
+		uint32_t v0 = box_no++ * 8 + 1;
+		f << "v " << lo[0] << " " << lo[1] << " " << lo[2] << "\n" << "v " << hi[0] << " " << lo[1] << " " << lo[2] << "\n"
+		  << "v " << hi[0] << " " << hi[1] << " " << lo[2] << "\n" << "v " << lo[0] << " " << hi[1] << " " << lo[2] << "\n"
+		  << "v " << lo[0] << " " << lo[1] << " " << hi[2] << "\n" << "v " << hi[0] << " " << lo[1] << " " << hi[2] << "\n"
+		  << "v " << hi[0] << " " << hi[1] << " " << hi[2] << "\n" << "v " << lo[0] << " " << hi[1] << " " << hi[2] << "\n";
+		f << "g level" << depth + 1 << "\n";
+		static const int q[6][4] = {{0, 1, 2, 3}, {1, 5, 6, 2}, {0, 1, 5, 4}, {3, 2, 6, 7}, {4, 7, 6, 5}, {4, 0, 3, 7}};
+		for (auto &face : q) f << "f " << v0 + face[0] << " " << v0 + face[1] << " " << v0 + face[2] << " " << v0 + face[3] << "\n";
+	};
+	struct Item {
+		uint32_t node, depth;
+	};
+	std::vector<Item> todo{{t.root, 0}};
+	while (!todo.empty()) {
+		Item it = todo.back();
+		todo.pop_back();
+		const rtgi_node56 &nd = t.nodes[it.node];
+		if (nd.link_r < 0 || it.depth >= max_depth) continue;
+		emit(nd.box_l, it.depth);
+		emit(nd.box_r, it.depth);
+		todo.push_back({(uint32_t)nd.link_r, it.depth + 1});  // left subtree is written first
+		todo.push_back({(uint32_t)nd.link_l, it.depth + 1});
+	}
+	return true;
+}
+
+}  // namespace rtgi

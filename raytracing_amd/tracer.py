@@ -1,0 +1,205 @@
+"""ctypes binding of librtgi_hip.so (include/rtgi_hip.h) and a Python mirror of the reference's tracer
+interface: ``build(scene)``, ``closest_hit``, ``any_hit``, ``interprete`` (libgi/rt.h:91-107 and
+libgi/wavefront-rt.h:10-16 of the reference tree "Assignment 3/rtgi-2021-a03-ref/").
+
+There is no CPU fallback: if the HIP library is missing or no GPU is present, the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librtgi_hip.so")
+
+RAY_DTYPE = np.dtype([("o", "<f4", (3,)), ("d", "<f4", (3,)), ("t_min", "<f4"), ("t_max", "<f4")])
+HIT_DTYPE = np.dtype([("t", "<f4"), ("beta", "<f4"), ("gamma", "<f4"), ("ref", "<u4")])
+NODE56_DTYPE = np.dtype([("box_l", "<f4", (6,)), ("box_r", "<f4", (6,)), ("link_l", "<i4"), ("link_r", "<i4")])
+assert RAY_DTYPE.itemsize == 32 and HIT_DTYPE.itemsize == 16 and NODE56_DTYPE.itemsize == 56
+
+FLT_MAX = float(np.finfo(np.float32).max)
+LAYOUT = {"flat": 0, "indexed": 1}
+
+# every symbol include/rtgi_hip.h declares
+EXPORTS = [
+    "rtgi_hip_device_count", "rtgi_hip_create", "rtgi_hip_destroy", "rtgi_hip_interprete", "rtgi_hip_build",
+    "rtgi_hip_upload_bvh", "rtgi_hip_num_nodes", "rtgi_hip_num_index", "rtgi_hip_root", "rtgi_hip_depth",
+    "rtgi_hip_get_nodes", "rtgi_hip_get_triangle_order", "rtgi_hip_closest_hit", "rtgi_hip_any_hit",
+    "rtgi_hip_closest_hit_device", "rtgi_hip_any_hit_device", "rtgi_hip_last_error",
+]
+
+
+class RtgiHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load librtgi_hip.so; raises if it has not been built (there is no other implementation)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RtgiHipError("%s is missing: build it with `make -C raytracing_amd/csrc` "
+                               "(or __graft_entry__.build())" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp, u32, i32, sz, cp = C.c_void_p, C.c_uint32, C.c_int, C.c_size_t, C.c_char_p
+        L.rtgi_hip_device_count.restype = i32
+        L.rtgi_hip_create.argtypes = [i32, i32, i32]
+        L.rtgi_hip_create.restype = vp
+        L.rtgi_hip_destroy.argtypes = [vp]
+        L.rtgi_hip_destroy.restype = None
+        L.rtgi_hip_interprete.argtypes = [vp, cp, cp]
+        L.rtgi_hip_build.argtypes = [vp, vp, sz, u32, vp, sz, u32]
+        L.rtgi_hip_upload_bvh.argtypes = [vp, vp, u32, u32, vp, u32, vp, sz, u32, vp, sz, u32]
+        for name in ("num_nodes", "num_index", "root", "depth"):
+            f = getattr(L, "rtgi_hip_" + name)
+            f.argtypes = [vp]
+            f.restype = u32
+        L.rtgi_hip_get_nodes.argtypes = [vp, vp]
+        L.rtgi_hip_get_triangle_order.argtypes = [vp, vp]
+        L.rtgi_hip_closest_hit.argtypes = [vp, vp, u32, vp]
+        L.rtgi_hip_any_hit.argtypes = [vp, vp, u32, vp]
+        L.rtgi_hip_closest_hit_device.argtypes = [vp, vp, u32, vp, vp, vp]
+        L.rtgi_hip_any_hit_device.argtypes = [vp, vp, u32, vp, vp, vp]
+        L.rtgi_hip_last_error.argtypes = [vp]
+        L.rtgi_hip_last_error.restype = cp
+        _lib = L
+    return _lib
+
+
+def device_count():
+    return lib().rtgi_hip_device_count()
+
+
+def as_rays(rays):
+    """(n, 8) float32 rows o.xyz, d.xyz, t_min, t_max (or a RAY_DTYPE array) -> contiguous (n, 8) float32."""
+    a = np.asarray(rays)
+    if a.dtype == RAY_DTYPE:
+        a = a.view(np.float32).reshape(-1, 8)
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.ndim != 2 or a.shape[1] != 8:
+        raise ValueError("rays must be (n, 8) float32")
+    return a
+
+
+class HipBvhTracer:
+    """The object `raytracer bbvh [indexed] [esc]` would create (driver/interaction.cpp:177-203), with the
+    traversal on the GPU. Scene = (positions (nv, 3) float32, triangles (nt, 3) uint32)."""
+
+    def __init__(self, layout="flat", esc=False, device=0):
+        self._h = lib().rtgi_hip_create(device, LAYOUT[layout], int(esc))
+        if not self._h:
+            raise RtgiHipError(lib().rtgi_hip_last_error(None).decode())
+        self.layout, self.esc, self.device = layout, esc, device
+        self.n_triangles = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rtgi_hip_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc < 0:
+            raise RtgiHipError("%s (code %d)" % (lib().rtgi_hip_last_error(self._h).decode(), rc))
+        return rc
+
+    # -- ray_tracer interface ---------------------------------------------------------------------
+    def interprete(self, command, args=""):
+        """Returns True if the command was consumed (bvh2.cpp:503-555). Malformed arguments raise."""
+        return self._check(lib().rtgi_hip_interprete(self._h, command.encode(), args.encode())) == 1
+
+    def build(self, pos, tri):
+        pos = np.ascontiguousarray(pos, dtype=np.float32)
+        tri = np.ascontiguousarray(tri, dtype=np.uint32)
+        if pos.ndim != 2 or pos.shape[1] != 3 or tri.ndim != 2 or tri.shape[1] != 3:
+            raise ValueError("pos must be (nv, 3) float32 and tri (nt, 3) uint32")
+        self._check(lib().rtgi_hip_build(self._h, pos.ctypes.data, 12, len(pos), tri.ctypes.data, 12, len(tri)))
+        self.n_triangles = len(tri)
+
+    def upload_bvh(self, nodes, root, index, pos, tri):
+        nodes = np.ascontiguousarray(nodes, dtype=NODE56_DTYPE)
+        pos = np.ascontiguousarray(pos, dtype=np.float32)
+        tri = np.ascontiguousarray(tri, dtype=np.uint32)
+        idx = None if index is None else np.ascontiguousarray(index, dtype=np.uint32)
+        self._check(lib().rtgi_hip_upload_bvh(
+            self._h, nodes.ctypes.data, len(nodes), int(root), None if idx is None else idx.ctypes.data,
+            0 if idx is None else len(idx), pos.ctypes.data, 12, len(pos), tri.ctypes.data, 12, len(tri)))
+        self.n_triangles = len(tri)
+
+    # -- tree read-back -----------------------------------------------------------------------------
+    @property
+    def root(self):
+        return lib().rtgi_hip_root(self._h)
+
+    @property
+    def depth(self):
+        return lib().rtgi_hip_depth(self._h)
+
+    def nodes(self):
+        out = np.zeros(lib().rtgi_hip_num_nodes(self._h), NODE56_DTYPE)
+        if len(out):
+            self._check(lib().rtgi_hip_get_nodes(self._h, out.ctypes.data))
+        return out
+
+    def triangle_order(self):
+        out = np.zeros(lib().rtgi_hip_num_index(self._h), np.uint32)
+        if len(out):
+            self._check(lib().rtgi_hip_get_triangle_order(self._h, out.ctypes.data))
+        return out
+
+    # -- batch interface (wf::batch_ray_tracer), host buffers ------------------------------------------
+    def closest_hit(self, rays):
+        rays = as_rays(rays)
+        hits = np.zeros(len(rays), HIT_DTYPE)
+        self._check(lib().rtgi_hip_closest_hit(self._h, rays.ctypes.data, len(rays), hits.ctypes.data))
+        return hits
+
+    def any_hit(self, rays):
+        rays = as_rays(rays)
+        occ = np.zeros(len(rays), np.uint8)
+        self._check(lib().rtgi_hip_any_hit(self._h, rays.ctypes.data, len(rays), occ.ctypes.data))
+        return occ
+
+    # -- batch interface, device buffers (torch tensors on this tracer's GPU) --------------------------
+    def closest_hit_device(self, d_rays, d_hits, d_counts=None, stream=None):
+        """d_rays: float32 (n, 8) cuda tensor; d_hits: float32 (n, 4) cuda tensor (t, beta, gamma, ref bits);
+        d_counts: optional int32 (n, 2). Asynchronous on `stream` (default: torch's current stream)."""
+        n = self._check_device_args(d_rays, d_hits, 4, d_counts)
+        self._check(lib().rtgi_hip_closest_hit_device(
+            self._h, d_rays.data_ptr(), n, d_hits.data_ptr(), d_counts.data_ptr() if d_counts is not None else None,
+            self._stream(stream)))
+
+    def any_hit_device(self, d_rays, d_occluded, d_counts=None, stream=None):
+        n = self._check_device_args(d_rays, d_occluded, 1, d_counts)
+        self._check(lib().rtgi_hip_any_hit_device(
+            self._h, d_rays.data_ptr(), n, d_occluded.data_ptr(), d_counts.data_ptr() if d_counts is not None else None,
+            self._stream(stream)))
+
+    def _check_device_args(self, d_rays, d_out, out_width, d_counts):
+        import torch
+        if not (d_rays.is_cuda and d_out.is_cuda) or d_rays.device.index != self.device or d_out.device.index != self.device:
+            raise ValueError("ray and output tensors must live on cuda:%d" % self.device)
+        if d_rays.dtype != torch.float32 or d_rays.dim() != 2 or d_rays.shape[1] != 8 or not d_rays.is_contiguous():
+            raise ValueError("d_rays must be a contiguous float32 (n, 8) tensor")
+        n = d_rays.shape[0]
+        if out_width == 4:
+            ok = d_out.dtype == torch.float32 and tuple(d_out.shape) == (n, 4)
+        else:
+            ok = d_out.dtype == torch.uint8 and d_out.numel() == n
+        if not ok or not d_out.is_contiguous():
+            raise ValueError("output tensor has the wrong dtype or shape for %d rays" % n)
+        if d_counts is not None:
+            if d_counts.dtype != torch.int32 or tuple(d_counts.shape) != (n, 2) or not d_counts.is_contiguous() \
+                    or not d_counts.is_cuda or d_counts.device.index != self.device:
+                raise ValueError("d_counts must be a contiguous int32 (n, 2) tensor on the tracer's GPU")
+        return n
+
+    def _stream(self, stream):
+        import torch
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device)
+        return C.c_void_p(stream.cuda_stream)

@@ -1,0 +1,212 @@
+"""Parity of the HIP traversal with the CPU oracle, through the C ABI, on a real MI355X.
+
+Bar: bit-exact. The kernels keep the reference's visiting order and arithmetic, so t, beta, gamma and
+the triangle id must be identical to the oracle's for every ray, including exact ties; the per-ray
+counts of inner nodes popped and triangles tested must be identical as well."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from raytracing_amd import scenes, tracer
+from tests.util import FLT_MAX, assert_hits_equal, obj_scene, rays_toward_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _configure(t, cmds):
+    for c in cmds:
+        assert t.interprete("bvh", c)
+
+
+def _oracle_for(pos, tri, layout, esc, cmds):
+    kw = dict(layout=layout, esc=esc, split="om", planes=0, max_tris=1)
+    for c in cmds:
+        p = c.split()
+        if p[0] in ("om", "sm"):
+            kw["split"] = p[0]
+        elif p[0] == "sah":
+            kw["split"], kw["planes"] = "sah", int(p[1])
+        elif p[0] == "triangles":
+            kw["max_tris"] = 1 if p[1] == "single" else int(p[2])
+    return orc.Bbvh(pos, tri, **kw)
+
+
+def _mixed_rays(pos, n, seed):
+    """Rays aimed at the scene, rays from inside it, shadow-style rays with a finite t_max."""
+    a = rays_toward_scene(pos, n // 2, seed)
+    lo, hi = pos.min(0), pos.max(0)
+    b = scenes.random_rays(n - n // 2, seed + 1)
+    b[:, 0:3] = lo + (b[:, 0:3] + 10.0) / 20.0 * (hi - lo)
+    rays = np.concatenate([a, b])
+    rs = np.random.RandomState(seed + 2)
+    short = rs.rand(len(rays)) < 0.3
+    rays[short, 7] = rs.uniform(0.05, 1.0, size=short.sum()) * float(np.linalg.norm(hi - lo))
+    return rays
+
+
+def _check(pos, tri, rays, layout="flat", esc=False, cmds=()):
+    t = tracer.HipBvhTracer(layout=layout, esc=esc)
+    _configure(t, cmds)
+    t.build(pos, tri)
+    o = _oracle_for(pos, tri, layout, esc, cmds)
+    assert t.nodes().tobytes() == o.nodes().tobytes()
+    want, want_counts = o.closest_hit(rays, counts=True)
+    got = t.closest_hit(rays)
+    assert_hits_equal(got, want, "%s esc=%s %s" % (layout, esc, list(cmds)))
+    want_any, want_any_counts = o.any_hit(rays, counts=True)
+    assert (t.any_hit(rays) == want_any).all()
+    _check_device_path(t, rays, want, want_counts, want_any, want_any_counts)
+    t.close()
+
+
+def _check_device_path(t, rays, want, want_counts, want_any, want_any_counts):
+    import torch
+    d_rays = torch.from_numpy(rays).cuda()
+    d_hits = torch.empty((len(rays), 4), dtype=torch.float32, device="cuda")
+    d_cnt = torch.zeros((len(rays), 2), dtype=torch.int32, device="cuda")
+    t.closest_hit_device(d_rays, d_hits, d_cnt)
+    torch.cuda.synchronize()
+    got = d_hits.cpu().numpy().view(tracer.HIT_DTYPE).reshape(-1)
+    assert_hits_equal(got, want, "device path")
+    cnt = d_cnt.cpu().numpy().astype(np.uint32)
+    assert (cnt == want_counts[:, 0:2]).all()
+    d_occ = torch.empty(len(rays), dtype=torch.uint8, device="cuda")
+    d_cnt.zero_()
+    t.any_hit_device(d_rays, d_occ, d_cnt)
+    torch.cuda.synchronize()
+    assert (d_occ.cpu().numpy() == want_any).all()
+    assert (d_cnt.cpu().numpy().astype(np.uint32) == want_any_counts[:, 0:2]).all()
+
+
+@pytest.mark.parametrize("name", ["tri.obj", "2tri.obj", "brdf-test-noal.obj", "mis.obj"])
+def test_render_data_scenes(name):
+    pos, tri, _ = obj_scene(name)
+    rays = _mixed_rays(pos, 20000, seed=5)
+    _check(pos, tri, rays, "flat")
+    _check(pos, tri, rays, "indexed", cmds=["sah 4"])
+    if len(tri) > 2:
+        _check(pos, tri, rays, "indexed", esc=True)
+
+
+VARIANTS = [
+    ("flat", False, ()),
+    ("indexed", False, ("sm",)),
+    ("indexed", False, ("sah 16",)),
+    ("indexed", False, ("sah 8", "triangles multiple 4")),
+    ("flat", False, ("om", "triangles multiple 3")),
+    ("indexed", True, ()),
+]
+
+
+@pytest.mark.parametrize("layout,esc,cmds", VARIANTS)
+def test_generated_scenes(layout, esc, cmds):
+    for pos, tri, _ in (scenes.soup(20000, seed=1), scenes.cornell(4), scenes.sponza_class(20000),
+                        scenes.terrain_objects(20000)):
+        _check(pos, tri, _mixed_rays(pos, 30000, seed=9), layout, esc, cmds)
+
+
+def test_deep_tree_spills_the_lds_stack():
+    # spatial-median split of a skewed distribution: depth far beyond the 16 LDS entries and beyond the
+    # reference's own 25-slot stack
+    pos, tri, _ = scenes.skewed(60000, seed=5)
+    t = tracer.HipBvhTracer(layout="indexed")
+    t.interprete("bvh", "sm")
+    t.build(pos, tri)
+    assert t.depth > 25
+    rays = _mixed_rays(pos, 40000, seed=2)
+    o = orc.Bbvh(pos, tri, layout="indexed", split="sm")
+    want, counts, max_stack = o.closest_hit(rays, counts=True, max_stack=True)
+    assert max_stack.max() > 17        # the LDS part of the stack alone would not have been enough
+    assert_hits_equal(t.closest_hit(rays), want, "deep tree")
+    assert (t.any_hit(rays) == o.any_hit(rays)).all()
+
+
+def test_axis_parallel_rays_and_origins_on_box_planes():
+    # d components of exactly 0 give id = +-inf, and origins on box planes then give 0 * inf = NaN in the
+    # slab test (libgi/intersect.h:210-228); the selects must resolve exactly like the reference's.
+    pos, tri, _ = scenes.cornell(4)
+    rs = np.random.RandomState(3)
+    n = 20000
+    rays = np.zeros((n, 8), np.float32)
+    grid = np.linspace(-1, 1, 9)
+    rays[:, 0:3] = rs.choice(grid, size=(n, 3))            # origins on wall and box planes
+    axis = rs.randint(0, 3, n)
+    kind = rs.randint(0, 3, n)
+    d = rs.normal(size=(n, 3))
+    for k in range(3):                                      # kind 0: one zero component, 1: two zeros
+        d[(kind == 0) & (axis == k), k] = 0.0
+        m = (kind == 1) & (axis == k)
+        d[m, (k + 1) % 3] = 0.0
+        d[m, (k + 2) % 3] = 0.0
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays[:, 3:6] = d
+    rays[:, 6], rays[:, 7] = 1e-4, FLT_MAX
+    rays[::7, 3:6] = np.where(rays[::7, 3:6] == 0, -0.0, rays[::7, 3:6])   # negative zeros: id = -inf
+    for layout, cmds in (("flat", ()), ("indexed", ("sah 8",))):
+        _check(pos, tri, rays, layout, False, cmds)
+
+
+def test_batch_sizes_and_argument_checks():
+    import torch
+    pos, tri, _ = scenes.soup(5000, seed=4)
+    t = tracer.HipBvhTracer(layout="indexed")
+    with pytest.raises(tracer.RtgiHipError):
+        t.closest_hit(scenes.random_rays(8))               # nothing built yet
+    t.build(pos, tri)
+    o = orc.Bbvh(pos, tri, layout="indexed")
+    assert len(t.closest_hit(np.zeros((0, 8), np.float32))) == 0
+    for n in (1, 63, 64, 65, 255, 257, 4097, 100003):
+        rays = scenes.random_rays(n, seed=n)
+        assert_hits_equal(t.closest_hit(rays), o.closest_hit(rays), "n=%d" % n)
+        assert (t.any_hit(rays) == o.any_hit(rays)).all()
+    # a ray buffer that is not 16-byte aligned is refused, not read
+    buf = torch.zeros(8 * 16 + 1, dtype=torch.float32, device="cuda")
+    rc = tracer.lib().rtgi_hip_closest_hit_device(t._h, buf.data_ptr() + 4, 16, buf.data_ptr(), None, None)
+    assert rc == -1
+
+
+def test_upload_of_a_foreign_tree():
+    pos, tri, _ = scenes.soup(8000, seed=6)
+    o = orc.Bbvh(pos, tri, layout="indexed", split="sah", planes=8)
+    t = tracer.HipBvhTracer(layout="indexed")
+    t.upload_bvh(o.nodes(), o.root, o.index(), pos, tri)
+    rays = scenes.random_rays(20000, seed=12)
+    assert_hits_equal(t.closest_hit(rays), o.closest_hit(rays), "uploaded tree")
+
+
+def test_full_size_soup_properties():
+    # BASELINE-size scene (2^20 triangles): oracle on a sample, size-independent properties on the rest
+    import torch
+    pos, tri, _ = scenes.soup(1 << 20, seed=1)
+    t = tracer.HipBvhTracer(layout="indexed")
+    t.build(pos, tri)
+    n = 1 << 20
+    rays = scenes.random_rays(n, seed=7)
+    d_rays = torch.from_numpy(rays).cuda()
+    d_hits = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+    d_occ = torch.empty(n, dtype=torch.uint8, device="cuda")
+    t.closest_hit_device(d_rays, d_hits)
+    t.any_hit_device(d_rays, d_occ)
+    torch.cuda.synchronize()
+    hits = d_hits.cpu().numpy().view(tracer.HIT_DTYPE).reshape(-1)
+    occ = d_occ.cpu().numpy()
+    valid = hits["t"] != FLT_MAX
+    assert (occ == valid).all()                                     # any_hit <=> closest_hit finds something
+    assert 0.3 < valid.mean() < 0.7
+    assert (hits["beta"][valid] > 0).all() and (hits["gamma"][valid] > 0).all()
+    assert (hits["beta"][valid] + hits["gamma"][valid] <= 1).all()
+    assert (hits["ref"][valid] < len(tri)).all()
+    # shortening every hit ray to just before its hit must turn it into a miss (nothing closer exists)
+    short = rays[valid].copy()
+    short[:, 7] = hits["t"][valid]
+    assert (t.closest_hit(short)["t"] == FLT_MAX).all()
+    # the barycentric point lies on the ray: A + beta (B-A) + gamma (C-A) == o + t d
+    v = pos[tri[hits["ref"][valid]]].astype(np.float64)
+    b, g = hits["beta"][valid, None].astype(np.float64), hits["gamma"][valid, None].astype(np.float64)
+    p_tri = v[:, 0] * (1 - b - g) + v[:, 1] * b + v[:, 2] * g
+    p_ray = rays[valid, 0:3] + hits["t"][valid, None].astype(np.float64) * rays[valid, 3:6]
+    assert np.abs(p_tri - p_ray).max() < 1e-3
+    # oracle on a sample of the same rays
+    o = orc.Bbvh(pos, tri, layout="indexed")
+    sample = np.arange(0, n, 64)
+    assert_hits_equal(hits[sample], o.closest_hit(rays[sample]), "2^20 soup sample")
