@@ -43,6 +43,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RtgiHipError("%s is missing: build it with `make -C raytracing_amd/csrc` "
                                "(or __graft_entry__.build())" % LIB_PATH)
+        # PyTorch ships its own copy of the HIP runtime. Two copies in one process fight over the GPU, so
+        # let torch load its copy first; librtgi_hip.so then binds to that one (same soname).
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         vp, u32, i32, sz, cp = C.c_void_p, C.c_uint32, C.c_int, C.c_size_t, C.c_char_p
         L.rtgi_hip_device_count.restype = i32

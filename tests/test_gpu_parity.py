@@ -105,20 +105,55 @@ def test_generated_scenes(layout, esc, cmds):
         _check(pos, tri, _mixed_rays(pos, 30000, seed=9), layout, esc, cmds)
 
 
+def _chain_scene(n=60):
+    """Triangles facing +x at x = -2^i with sizes growing alike: a spatial-median split peels off the
+    leftmost triangle at every level, so the tree is a chain of depth n - 1."""
+    tris = []
+    for i in range(n):
+        x, s = -(2.0 ** i), 0.25 * 2.0 ** i
+        tris.append([[x, -s, -s], [x, s, -s], [x, 0.0, s]])
+    return scenes._finish(np.array(tris))
+
+
 def test_deep_tree_spills_the_lds_stack():
-    # spatial-median split of a skewed distribution: depth far beyond the 16 LDS entries and beyond the
-    # reference's own 25-slot stack
-    pos, tri, _ = scenes.skewed(60000, seed=5)
+    # a chain-shaped tree: rays along -x enter every box, so the pending-node stack grows to the tree depth,
+    # far beyond the 16 entries kept in LDS and beyond the reference's own 25 slots
+    pos, tri, _ = _chain_scene(60)
+    rs = np.random.RandomState(8)
+    n = 5000
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, 0] = 10.0
+    rays[:, 1:3] = rs.uniform(-0.2, 0.2, size=(n, 2))
+    d = np.concatenate([-np.ones((n, 1)), rs.uniform(-0.01, 0.01, size=(n, 2))], axis=1)
+    d[::5] *= -1                                   # some rays point away and miss everything
+    rays[:, 3:6] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays[:, 6], rays[:, 7] = 1e-4, FLT_MAX
+    rays[1::3, 0] = -rs.uniform(1, 2.0 ** 40, size=len(rays[1::3]))   # origins between the sheets
     t = tracer.HipBvhTracer(layout="indexed")
     t.interprete("bvh", "sm")
     t.build(pos, tri)
-    assert t.depth > 25
-    rays = _mixed_rays(pos, 40000, seed=2)
+    assert t.depth >= 40
     o = orc.Bbvh(pos, tri, layout="indexed", split="sm")
     want, counts, max_stack = o.closest_hit(rays, counts=True, max_stack=True)
-    assert max_stack.max() > 17        # the LDS part of the stack alone would not have been enough
-    assert_hits_equal(t.closest_hit(rays), want, "deep tree")
-    assert (t.any_hit(rays) == o.any_hit(rays)).all()
+    assert max_stack.max() > 40
+    assert (want["t"] != FLT_MAX).sum() > n // 2
+    assert_hits_equal(t.closest_hit(rays), want, "chain tree")
+    want_any, any_counts = o.any_hit(rays, counts=True)
+    assert (t.any_hit(rays) == want_any).all()
+    _check_device_path(t, rays, want, counts, want_any, any_counts)
+
+
+def test_skewed_scene_with_unbalanced_trees():
+    pos, tri, _ = scenes.skewed(60000, seed=5)
+    rays = _mixed_rays(pos, 40000, seed=2)
+    for cmds in (("sm",), ("sah 16",)):
+        t = tracer.HipBvhTracer(layout="indexed")
+        _configure(t, cmds)
+        t.build(pos, tri)
+        assert t.depth > 25
+        o = _oracle_for(pos, tri, "indexed", False, cmds)
+        assert_hits_equal(t.closest_hit(rays), o.closest_hit(rays), "skewed %s" % (cmds,))
+        assert (t.any_hit(rays) == o.any_hit(rays)).all()
 
 
 def test_axis_parallel_rays_and_origins_on_box_planes():
