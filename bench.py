@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""Ray-traversal throughput of the HIP backend: Mrays/s of closest_hit on incoherent first-bounce rays.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched through torch.distributed.run)
+
+One step = one closest_hit pass over one batch of diffuse-bounce rays that already live in GPU memory
+(workload "soup1m_bounce": 2^20-triangle seeded soup, 1920x1080 camera rays from the centre of the scene,
+one cosine-weighted bounce off every primary hit). With N GPUs every rank holds the whole BVH and traces
+its own sample's bounce batch (sharding by sample index: weak scaling, no collective on the data path).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, vendor peak
+
+WORKLOADS = {
+    # name: (scene generator, kwargs, camera position, direction, up)
+    "soup1m_bounce": ("soup", dict(n_tris=1 << 20, seed=1), (0, 0, 0), (0, 0, -1), (0, 1, 0)),
+    "soup260k_bounce": ("soup", dict(n_tris=1 << 18, seed=1), (0, 0, 0), (0, 0, -1), (0, 1, 0)),
+    "terrain1m_bounce": ("terrain_objects", dict(target_tris=1 << 20, seed=3), (0, 6, 14), (0, -0.35, -0.937), (0, 1, 0)),
+    "sponza260k_bounce": ("sponza_class", dict(target_tris=262144, seed=0), (-516, 300, 0), (1, 0, 0), (0, 1, 0)),
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="soup1m_bounce", choices=sorted(WORKLOADS))
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--layout", default="flat", choices=["flat", "indexed"])
+    ap.add_argument("--bvh", default="", help="extra 'bvh ...' commands separated by ';', e.g. 'sah 16'")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    return ap.parse_args()
+
+
+def build_workload(args, rank, device):
+    """Scene, tracer and this rank's bounce batch. Everything here is outside the timed region."""
+    import torch
+    from raytracing_amd import scenes, tracer, wavefront
+    gen, kw, cam_pos, cam_dir, cam_up = WORKLOADS[args.workload]
+    pos, tri, _ = getattr(scenes, gen)(**kw)
+    t = tracer.HipBvhTracer(layout=args.layout, device=device)
+    for cmd in [c.strip() for c in args.bvh.split(";") if c.strip()]:
+        t.interprete("bvh", cmd)
+    t0 = time.time()
+    t.build(pos, tri)
+    build_s = time.time() - t0
+    tri_original = tri
+    if args.layout == "flat":  # commit_shuffled_triangles: hit ids index the permuted list
+        tri = tri[t.triangle_order()]
+    # sample index = rank: jittered camera rays, then one diffuse bounce
+    jitter = np.stack([wavefront.uniform01(np.arange(args.width * args.height), 100, rank) - 0.5,
+                       wavefront.uniform01(np.arange(args.width * args.height), 101, rank) - 0.5], 1)
+    primary = wavefront.camera_rays(cam_dir / np.linalg.norm(cam_dir), cam_pos, cam_up, 65.0, args.width, args.height,
+                                    jitter.reshape(args.height, args.width, 2).astype(np.float32))
+    d_primary = torch.from_numpy(primary).to("cuda:%d" % device)
+    d_hits = torch.empty((len(primary), 4), dtype=torch.float32, device=d_primary.device)
+    t.closest_hit_device(d_primary, d_hits)
+    torch.cuda.synchronize(device)
+    hits = d_hits.cpu().numpy().view(tracer.HIT_DTYPE).reshape(-1)
+    bounce, _ = wavefront.bounce_rays(pos, tri, primary, hits, seed=rank, bounce=1)
+    return dict(tracer=t, pos=pos, tri=tri, tri_original=tri_original, primary=primary, bounce=bounce, build_s=build_s,
+                primary_hit_rate=float((hits["t"] != tracer.FLT_MAX).mean()))
+
+
+def algorithmic_bytes(t, d_rays, layout):
+    """Bytes the reference's data structures would move for these rays: 32 B ray in, 16 B hit out, 56 B per
+    inner node popped (sizeof(node), rt/bbvh-base/bvh.h:39-47), 52 B per triangle tested (16-B triangle
+    record + three 12-B positions, libgi/intersect.h:20-33), 4 B more per test through index[] (bvh.h:102-106).
+    The pops and tests are counted by the kernel itself; tests check them against the oracle's counts."""
+    import torch
+    n = d_rays.shape[0]
+    d_hits = torch.empty((n, 4), dtype=torch.float32, device=d_rays.device)
+    d_cnt = torch.zeros((n, 2), dtype=torch.int32, device=d_rays.device)
+    t.closest_hit_device(d_rays, d_hits, d_cnt)
+    torch.cuda.synchronize(d_rays.device)
+    s = d_cnt.sum(0, dtype=torch.int64).cpu().numpy()
+    per_tri = 52 + (4 if layout == "indexed" else 0)
+    total = 48 * n + 56 * int(s[0]) + per_tri * int(s[1])
+    hit_rate = float((d_hits[:, 0] != float(np.finfo(np.float32).max)).float().mean().item())
+    return total, float(s[0]) / n, float(s[1]) / n, hit_rate
+
+
+def cpu_baseline(args, w):
+    """The CPU oracle (restated reference traversal, all host cores) on a bounded sample of the same rays."""
+    from oracle import oracle as orc
+    # the oracle permutes the triangle list itself for the flat layout: hand it the original order
+    o = orc.Bbvh(w["pos"], w["tri_original"], layout=args.layout, **_oracle_split(args.bvh))
+    rays = w["bounce"]
+    o.closest_hit(rays[:20000])  # warm-up: thread pool, caches
+    passes, dt, t0 = 0, 0.0, time.time()
+    while dt < args.cpu_seconds:  # whole passes over the batch until the time budget is used
+        o.closest_hit(rays)
+        passes += 1
+        dt = time.time() - t0
+    return {"value": round(passes * len(rays) / dt / 1e6, 4), "unit": "Mrays/s", "cores": orc.max_threads(), "kind": "port",
+            "sample": "%d passes over the same %d bounce rays in %.1f s; CPU restatement of the reference tracer, "
+                      "OpenMP schedule(dynamic,1024), no per-ray stats timers" % (passes, len(rays), dt)}
+
+
+def _oracle_split(bvh):
+    kw = dict(split="om", planes=0, max_tris=1)
+    for c in [c.strip() for c in bvh.split(";") if c.strip()]:
+        p = c.split()
+        if p[0] in ("om", "sm"):
+            kw["split"] = p[0]
+        elif p[0] == "sah":
+            kw["split"], kw["planes"] = "sah", int(p[1])
+        elif p[0] == "triangles":
+            kw["max_tris"] = 1 if p[1] == "single" else int(p[2])
+    return kw
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    elif args.gpus != 1:
+        raise SystemExit("--gpus %d needs to be launched through torch.distributed.run" % args.gpus)
+    device = local_rank
+    torch.cuda.set_device(device)
+
+    w = build_workload(args, rank, device)
+    t = w["tracer"]
+    d_rays = torch.from_numpy(w["bounce"]).to("cuda:%d" % device)
+    n = d_rays.shape[0]
+    d_hits = torch.empty((n, 4), dtype=torch.float32, device=d_rays.device)
+
+    total_bytes, pops, tests, hit_rate = algorithmic_bytes(t, d_rays, args.layout)
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        t.closest_hit_device(d_rays, d_hits)
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for e0, e1 in events:  # the launches go to torch's current stream, which is the stream the events are on
+        e0.record()
+        t.closest_hit_device(d_rays, d_hits)
+        e1.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in events]))
+
+    stats = torch.tensor([elapsed, float(n)], dtype=torch.float64, device="cuda:%d" % device)
+    if world > 1:
+        mx = stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = stats.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed, total_rays = float(mx[0].item()), float(sm[1].item())
+    else:
+        total_rays = float(n)
+
+    if rank == 0:
+        achieved = total_bytes / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mrays/sec (closest-hit, incoherent bounce)",
+            "value": round(total_rays * args.steps / elapsed / 1e6, 2),
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": args.workload,
+                "triangles": int(len(w["tri"])),
+                "bvh": ("%s %s" % (args.layout, args.bvh or "om")).strip(),
+                "resolution": "%dx%d" % (args.width, args.height),
+                "rays_per_step_per_gpu": int(n),
+                "sharding": "sample index per GPU, BVH replicated",
+                "inner_pops_per_ray": round(pops, 2),
+                "triangle_tests_per_ray": round(tests, 3),
+                "bounce_hit_rate": round(hit_rate, 4),
+                "primary_hit_rate": round(w["primary_hit_rate"], 4),
+                "bvh_build_s": round(w["build_s"], 2),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": _measured_traffic(args.workload),
+                "kernel": "trace_kernel<closest>",
+                "kernel_ms": round(kernel_ms, 4),
+                "algorithmic_bytes_per_launch": int(total_bytes),
+                "algorithmic_bytes_per_ray": round(total_bytes / n, 1),
+            },
+        }
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args, w)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _measured_traffic(workload):
+    """HBM bytes per launch from the rocprofv3 PMC passes kept under profiles/ (null until measured)."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(workload)
+    except (OSError, ValueError):
+        return None
+
+
+if __name__ == "__main__":
+    main()

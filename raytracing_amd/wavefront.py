@@ -1,0 +1,121 @@
+"""Ray populations around the tracer: camera rays, shadow rays and diffuse bounce rays.
+
+These are the callers' side of the hot path (gi/primary-hit.cpp:16-56 and libgi/wavefront-rt.h:90-102 of
+the reference tree "Assignment 3/rtgi-2021-a03-ref/"): they decide which rays the tracer sees. The reference
+has no path tracer, so the bounce rays follow this module's own definition (cosine-weighted about the
+normal that faces the incoming ray, counter-based random numbers); host implementation in numpy, used to
+prepare workloads and as the definition the device kernels are checked against.
+"""
+import numpy as np
+
+FLT_MAX = np.float32(np.finfo(np.float32).max)
+EPS = np.float32(1e-4)  # ray::eps, libgi/rt.h:21
+
+
+def camera_rays(cam_dir, cam_pos, cam_up, fovy, w, h, offsets=None):
+    """cam_ray of libgi/camera.cpp:11-22 for every pixel, y-major, in float32 like the reference.
+    offsets: optional (h, w, 2) sub-pixel jitter in [-0.5, 0.5). Returns (w*h, 8) float32 rays."""
+    f = np.float32
+    d, up = np.asarray(cam_dir, f), np.asarray(cam_up, f)
+    near_h = f(np.tan(f(np.pi) * f(fovy) * f(0.5) / f(180.0)))
+    near_w = f(f(w) / f(h)) * near_h
+
+    def cross(a, b):
+        return np.array([a[1] * b[2] - b[1] * a[2], a[2] * b[0] - b[2] * a[0], a[0] * b[1] - b[0] * a[1]], f)
+    U = cross(d, up)
+    V = cross(U, d)
+    xs = np.arange(w, dtype=f)[None, :] + f(0.5)
+    ys = np.arange(h, dtype=f)[:, None] + f(0.5)
+    if offsets is not None:
+        xs = xs + np.asarray(offsets, f)[..., 0]
+        ys = ys + np.asarray(offsets, f)[..., 1]
+    u = (near_w * (xs / f(w) * f(2.0) - f(1.0))).astype(f) + np.zeros((h, w), f)
+    v = (near_h * (ys / f(h) * f(2.0) - f(1.0))).astype(f) + np.zeros((h, w), f)
+    dirs = d[None, None, :] + U[None, None, :] * u[..., None] + V[None, None, :] * v[..., None]
+    dirs = dirs.astype(f)
+    sq = (dirs[..., 0] * dirs[..., 0] + dirs[..., 1] * dirs[..., 1]) + dirs[..., 2] * dirs[..., 2]
+    dirs = dirs * (f(1.0) / np.sqrt(sq, dtype=f))[..., None]
+    rays = np.empty((h * w, 8), f)
+    rays[:, 0:3] = np.asarray(cam_pos, f)
+    rays[:, 3:6] = dirs.reshape(-1, 3)
+    rays[:, 6] = EPS
+    rays[:, 7] = FLT_MAX
+    return rays
+
+
+def hit_points(pos, tri, hits):
+    """diff_geom::x of libgi/rt.cpp:9: (1 - beta - gamma) a + beta b + gamma c, float32."""
+    f = np.float32
+    v = pos[tri[hits["ref"]]]
+    b, g = hits["beta"][:, None], hits["gamma"][:, None]
+    return ((f(1.0) - b - g) * v[:, 0] + b * v[:, 1] + g * v[:, 2]).astype(f)
+
+
+def shadow_rays(points, light_pos):
+    """Shadow rays of gi/primary-hit.cpp:43-50: from the hit point towards a point light, ending EPS
+    before it (ray::length_exclusive, libgi/rt.h:26)."""
+    f = np.float32
+    to_light = (np.asarray(light_pos, f)[None, :] - points).astype(f)
+    sq = (to_light[:, 0] * to_light[:, 0] + to_light[:, 1] * to_light[:, 1]) + to_light[:, 2] * to_light[:, 2]
+    dist = np.sqrt(sq, dtype=f)
+    rays = np.empty((len(points), 8), f)
+    rays[:, 0:3] = points
+    rays[:, 3:6] = to_light * (f(1.0) / dist)[:, None]
+    rays[:, 6] = EPS
+    rays[:, 7] = dist - EPS
+    return rays
+
+
+def _hash_u32(x):
+    """Counter-based generator: a 32-bit integer finaliser (two multiply-xorshift rounds)."""
+    x = np.asarray(x, np.uint64) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x7FEB352D)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(15)
+    x = (x * np.uint64(0x846CA68B)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(16)
+    return x.astype(np.uint32)
+
+
+def uniform01(index, stream, seed=0):
+    """Uniform floats in [0, 1) keyed by (ray index, stream number, seed); 24 random bits each."""
+    key = _hash_u32(np.asarray(index, np.uint64) * np.uint64(0x9E3779B1) + np.uint64(stream) * np.uint64(0x85EBCA77)
+                    + np.uint64(seed) * np.uint64(0xC2B2AE3D))
+    key = _hash_u32(key ^ np.uint32(0x27D4EB2F))
+    return (key >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / (1 << 24))
+
+
+def bounce_rays(pos, tri, rays, hits, seed=0, bounce=1, ray_index=None):
+    """One diffuse bounce: for every ray that hit something, a new ray from the hit point into a
+    cosine-weighted random direction about the geometric normal that faces the incoming ray.
+    Returns (new rays (m, 8) float32, indices of the parent rays (m,))."""
+    f = np.float32
+    valid = np.flatnonzero(hits["t"] != FLT_MAX)
+    hv = hits[valid]
+    x = hit_points(pos, tri, hv)
+    v = pos[tri[hv["ref"]]].astype(f)
+    n = np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0]).astype(f)
+    n /= np.maximum(np.linalg.norm(n, axis=1, keepdims=True), f(1e-30))
+    d_in = rays[valid, 3:6]
+    flip = (n * d_in).sum(1) > 0
+    n[flip] = -n[flip]
+    idx = valid if ray_index is None else np.asarray(ray_index)[valid]
+    u1 = uniform01(idx, 2 * bounce, seed)
+    u2 = uniform01(idx, 2 * bounce + 1, seed)
+    r, phi = np.sqrt(u1, dtype=f), f(2 * np.pi) * u2
+    lx, ly = r * np.cos(phi), r * np.sin(phi)
+    lz = np.sqrt(np.maximum(f(0), f(1) - u1), dtype=f)
+    # orthonormal basis around n (branchless form of Duff et al.)
+    sign = np.where(n[:, 2] >= 0, f(1), f(-1))
+    a = f(-1) / (sign + n[:, 2])
+    b = n[:, 0] * n[:, 1] * a
+    t1 = np.stack([f(1) + sign * n[:, 0] * n[:, 0] * a, sign * b, -sign * n[:, 0]], 1)
+    t2 = np.stack([b, sign + n[:, 1] * n[:, 1] * a, -n[:, 1]], 1)
+    d = (t1 * lx[:, None] + t2 * ly[:, None] + n * lz[:, None]).astype(f)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    out = np.empty((len(valid), 8), f)
+    out[:, 0:3] = x
+    out[:, 3:6] = d
+    out[:, 6] = EPS
+    out[:, 7] = FLT_MAX
+    return out, valid
