@@ -44,6 +44,8 @@ def parse_args():
     ap.add_argument("--bvh", default="", help="extra 'bvh ...' commands separated by ';', e.g. 'sah 16'")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--presort", default="none", choices=["none", "morton", "octant_morton", "morton_octant", "random"],
+                    help="experiment: reorder the bounce batch on the host before the timed region")
     return ap.parse_args()
 
 
@@ -112,6 +114,32 @@ def cpu_baseline(args, w):
                       "OpenMP schedule(dynamic,1024), no per-ray stats timers" % (passes, len(rays), dt)}
 
 
+def presort(rays, how):
+    """Experiment: order rays by origin Morton code and/or direction octant."""
+    o = rays[:, 0:3].astype(np.float64)
+    lo, hi = o.min(0), o.max(0)
+    q = np.clip(((o - lo) / np.maximum(hi - lo, 1e-9) * 1023).astype(np.uint64), 0, 1023)
+
+    def spread(v):
+        v = (v | (v << np.uint64(16))) & np.uint64(0x030000FF)
+        v = (v | (v << np.uint64(8))) & np.uint64(0x0300F00F)
+        v = (v | (v << np.uint64(4))) & np.uint64(0x030C30C3)
+        v = (v | (v << np.uint64(2))) & np.uint64(0x09249249)
+        return v
+    morton = spread(q[:, 0]) | (spread(q[:, 1]) << np.uint64(1)) | (spread(q[:, 2]) << np.uint64(2))
+    octant = ((rays[:, 3] < 0).astype(np.uint64) | ((rays[:, 4] < 0).astype(np.uint64) << np.uint64(1))
+              | ((rays[:, 5] < 0).astype(np.uint64) << np.uint64(2)))
+    if how == "morton":
+        key = morton
+    elif how == "octant_morton":
+        key = (octant << np.uint64(30)) | morton
+    elif how == "morton_octant":
+        key = ((morton >> np.uint64(9)) << np.uint64(3)) | octant
+    else:
+        key = np.random.RandomState(0).permutation(len(rays)).astype(np.uint64)
+    return np.ascontiguousarray(rays[np.argsort(key, kind="stable")])
+
+
 def _oracle_split(bvh):
     kw = dict(split="om", planes=0, max_tris=1)
     for c in [c.strip() for c in bvh.split(";") if c.strip()]:
@@ -143,6 +171,8 @@ def main():
 
     w = build_workload(args, rank, device)
     t = w["tracer"]
+    if args.presort != "none":
+        w["bounce"] = presort(w["bounce"], args.presort)
     d_rays = torch.from_numpy(w["bounce"]).to("cuda:%d" % device)
     n = d_rays.shape[0]
     d_hits = torch.empty((n, 4), dtype=torch.float32, device=d_rays.device)

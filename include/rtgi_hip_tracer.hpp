@@ -1,0 +1,243 @@
+// rtgi_hip_tracer.hpp -- C++ host adapter: the GPU tracer behind the renderer's own tracer interfaces.
+//
+// Two ways to use this header:
+//  * inside the rtgi tree: define RTGI_HIP_USE_LIBGI before including it. It then includes libgi/rt.h,
+//    libgi/scene.h, libgi/wavefront-rt.h and derives from the renderer's individual_ray_tracer and
+//    wf::batch_ray_tracer, so that `scene.use(new hip_bvh_batch_tracer(...))` works unchanged;
+//  * stand-alone (this repository's tests and tools): it declares mirror types with the same names, member
+//    order and sizes as the renderer's (citations are file:line of "Assignment 3/rtgi-2021-a03-ref/").
+//
+// Everything below the interface is one C handle from rtgi_hip.h; there is no CPU traversal in here.
+#pragma once
+
+#include <cfloat>
+#include <cstdint>
+#include <cstring>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "rtgi_hip.h"
+
+#ifdef RTGI_HIP_USE_LIBGI
+#include "libgi/rt.h"
+#include "libgi/scene.h"
+#include "libgi/wavefront-rt.h"
+namespace rtgi_hip {
+using ::individual_ray_tracer;
+using ::ray;
+using ::ray_tracer;
+using ::scene;
+using ::triangle;
+using ::triangle_intersection;
+using ::vertex;
+namespace wf = ::wf;
+}  // namespace rtgi_hip
+#else
+namespace rtgi_hip {
+
+struct vec2 {
+	float x = 0, y = 0;
+};
+struct vec3 {
+	float x = 0, y = 0, z = 0;
+	vec3() {}
+	vec3(float x, float y, float z) : x(x), y(y), z(z) {}
+};
+
+struct ray {  // libgi/rt.h:20-27
+	static constexpr float eps = 1e-4f;
+	vec3 o, d, id;
+	float t_min = eps, t_max = FLT_MAX;
+	ray(const vec3 &o, const vec3 &d) : o(o), d(d), id(1.0f / d.x, 1.0f / d.y, 1.0f / d.z) {}
+	ray() {}
+	void length_exclusive(float len) { t_max = len - eps; }
+};
+
+struct vertex {  // libgi/rt.h:29-33
+	vec3 pos;
+	vec3 norm;
+	vec2 tc;
+};
+
+struct triangle {  // libgi/rt.h:35-38
+	uint32_t a, b, c;
+	uint32_t material_id;
+};
+
+struct triangle_intersection {  // libgi/rt.h:40-62
+	typedef unsigned int uint;
+	float t, beta, gamma;
+	uint ref;
+	triangle_intersection() : t(FLT_MAX), ref(0) {}
+	triangle_intersection(uint t) : t(FLT_MAX), ref(t) {}
+	bool valid() const { return t != FLT_MAX; }
+	void reset() {
+		t = FLT_MAX;
+		ref = 0;
+	}
+};
+
+struct scene {  // the part of libgi/scene.h:74-113 a tracer touches
+	std::vector<vertex> vertices;
+	std::vector<triangle> triangles;
+};
+
+class ray_tracer {  // libgi/rt.h:91-98
+protected:
+	rtgi_hip::scene *scene = nullptr;
+
+public:
+	virtual void build(rtgi_hip::scene *) = 0;
+	virtual bool interprete(const std::string &, std::istringstream &) { return false; }
+	virtual ~ray_tracer() {}
+};
+
+class individual_ray_tracer : public ray_tracer {  // libgi/rt.h:100-107
+public:
+	virtual triangle_intersection closest_hit(const ray &) = 0;
+	virtual bool any_hit(const ray &) = 0;
+};
+
+namespace wf {
+struct batch_ray_tracer : public ray_tracer {  // libgi/wavefront-rt.h:10-16
+	ray *rays = nullptr;
+	triangle_intersection *intersections = nullptr;
+	virtual void compute_closest_hit() = 0;
+	virtual void compute_any_hit() = 0;
+};
+}  // namespace wf
+
+}  // namespace rtgi_hip
+#endif
+
+namespace rtgi_hip {
+
+static_assert(sizeof(ray) == 44, "ray must keep the renderer's layout");
+static_assert(sizeof(vertex) == 32 && sizeof(triangle) == 16, "scene records must keep the renderer's layout");
+static_assert(sizeof(triangle_intersection) == sizeof(rtgi_hit), "hit records are copied verbatim");
+
+// Owner of one C handle; shared by the two adapter classes below.
+class hip_bvh_core {
+public:
+	// `raytracer hip [indexed] [esc] [device N]`: same tags as `raytracer bbvh` (driver/interaction.cpp:182-200)
+	hip_bvh_core(bool indexed, bool esc, int device = 0) : indexed(indexed) {
+		h = rtgi_hip_create(device, indexed ? RTGI_LAYOUT_INDEXED : RTGI_LAYOUT_FLAT, esc ? 1 : 0);
+		if (!h) throw std::runtime_error(std::string("rtgi_hip_create: ") + rtgi_hip_last_error(nullptr));
+	}
+	~hip_bvh_core() { rtgi_hip_destroy(h); }
+	hip_bvh_core(const hip_bvh_core &) = delete;
+	hip_bvh_core &operator=(const hip_bvh_core &) = delete;
+
+	// build(scene*), rt/bbvh-base/bvh2.cpp:27-63. For the flat layout the scene's triangle list is replaced by
+	// the permuted one, exactly like commit_shuffled_triangles (bvh2.cpp:172-180) does.
+	template <class Scene>
+	void build(Scene *s) {
+		check(rtgi_hip_build(h, &s->vertices[0].pos, sizeof(s->vertices[0]), (uint32_t)s->vertices.size(), &s->triangles[0].a,
+		                     sizeof(s->triangles[0]), (uint32_t)s->triangles.size()));
+		if (!indexed) {
+			std::vector<uint32_t> order(rtgi_hip_num_index(h));
+			check(rtgi_hip_get_triangle_order(h, order.data()));
+			auto shuffled = s->triangles;
+			for (size_t i = 0; i < order.size(); ++i) shuffled[i] = s->triangles[order[i]];
+			s->triangles = std::move(shuffled);
+		}
+	}
+
+	// interprete(command, in), bvh2.cpp:503-555. Errors are printed like the renderer's error() macro does
+	// (bvh2.cpp:15) and the command counts as consumed.
+	bool interprete(const std::string &command, std::istringstream &in) {
+		std::string rest;
+		std::getline(in, rest);
+		int rc = rtgi_hip_interprete(h, command.c_str(), rest.c_str());
+		if (rc < 0) {
+			fprintf(stderr, "command  (%s): %s\n", command.c_str(), rtgi_hip_last_error(h));
+			return true;
+		}
+		return rc == 1;
+	}
+
+	void closest_hit(const ray *rays, size_t n, triangle_intersection *out) {
+		pack(rays, n);
+		check(rtgi_hip_closest_hit(h, staged.data(), (uint32_t)n, reinterpret_cast<rtgi_hit *>(out)));
+	}
+	// compute_any_hit stores the bool through triangle_intersection(uint): t = FLT_MAX, ref = 0 or 1
+	// (libgi/wavefront-rt.h:79, libgi/rt.h:46)
+	void any_hit(const ray *rays, size_t n, triangle_intersection *out) {
+		pack(rays, n);
+		occluded.resize(n);
+		check(rtgi_hip_any_hit(h, staged.data(), (uint32_t)n, occluded.data()));
+		for (size_t i = 0; i < n; ++i) out[i] = triangle_intersection((unsigned int)occluded[i]);
+	}
+	rtgi_hip_tracer *handle() { return h; }
+
+private:
+	void check(int rc) {
+		if (rc < 0) throw std::runtime_error(std::string("rtgi_hip: ") + rtgi_hip_last_error(h));
+	}
+	void pack(const ray *rays, size_t n) {  // drop the derived member id: 44-byte rays -> 32-byte rays
+		staged.resize(n);
+		for (size_t i = 0; i < n; ++i) {
+			const ray &r = rays[i];
+			staged[i] = rtgi_ray{{r.o.x, r.o.y, r.o.z}, {r.d.x, r.d.y, r.d.z}, r.t_min, r.t_max};
+		}
+	}
+	rtgi_hip_tracer *h = nullptr;
+	bool indexed;
+	std::vector<rtgi_ray> staged;
+	std::vector<uint8_t> occluded;
+};
+
+// The batch interface is the one the GPU is built for: one launch per compute_*() call over n_rays rays.
+// The renderer sizes its ray buffers to the resolution (libgi/wavefront-rt.h:24-50); set_batch() tells the
+// tracer which buffers and how many rays the next compute_*() calls cover.
+class hip_bvh_batch_tracer : public wf::batch_ray_tracer {
+public:
+	hip_bvh_batch_tracer(bool indexed = false, bool esc = false, int device = 0) : core(indexed, esc, device) {}
+	void set_batch(ray *r, triangle_intersection *is, size_t n) {
+		rays = r;
+		intersections = is;
+		n_rays = n;
+	}
+	void build(rtgi_hip::scene *s) override {
+		this->scene = s;
+		core.build(s);
+	}
+	bool interprete(const std::string &command, std::istringstream &in) override { return core.interprete(command, in); }
+	void compute_closest_hit() override { core.closest_hit(rays, n_rays, intersections); }
+	void compute_any_hit() override { core.any_hit(rays, n_rays, intersections); }
+	hip_bvh_core core;
+
+private:
+	size_t n_rays = 0;
+};
+
+// Per-ray interface for the renderer's recursive algorithms (gi/primary-hit.cpp:21,36,50). Every call is a
+// one-ray batch on the GPU: correct, and slow by construction -- algorithms that care about speed use the
+// batch tracer above. Calls are serialised by an OpenMP critical section (build with -fopenmp, as the renderer is) because the renderer invokes the tracer from all of
+// its OpenMP threads (libgi/framebuffer.h:41-46).
+class hip_bvh_individual_tracer : public individual_ray_tracer {
+public:
+	hip_bvh_individual_tracer(bool indexed = false, bool esc = false, int device = 0) : core(indexed, esc, device) {}
+	void build(rtgi_hip::scene *s) override {
+		this->scene = s;
+		core.build(s);
+	}
+	bool interprete(const std::string &command, std::istringstream &in) override { return core.interprete(command, in); }
+	triangle_intersection closest_hit(const ray &r) override {
+		triangle_intersection out;
+#pragma omp critical(rtgi_hip_single_ray)
+		core.closest_hit(&r, 1, &out);
+		return out;
+	}
+	bool any_hit(const ray &r) override {
+		triangle_intersection out;
+#pragma omp critical(rtgi_hip_single_ray)
+		core.any_hit(&r, 1, &out);
+		return out.ref != 0;
+	}
+	hip_bvh_core core;
+};
+
+}  // namespace rtgi_hip

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <sstream>
@@ -381,11 +382,26 @@ bool validate_tree(HostTree &t, uint32_t n_triangles, std::string &err) {
 
 void flatten_tree(const HostTree &t, const SceneView &scene, int layout, FlatTree &out) {
 	const uint32_t n = (uint32_t)t.nodes.size();
-	// inner nodes keep their relative (pre-order) position
+	// Inner nodes are renumbered level by level (breadth first): the upper levels, which every ray visits,
+	// become one contiguous block (fully used cache lines, resident in every L2), and the two children of
+	// a node land in the same 128-byte line. RTGI_HIP_NODE_ORDER=dfs keeps the reference's pre-order.
 	std::vector<int32_t> inner_id(n, -1);
 	uint32_t n_inner = 0;
-	for (uint32_t i = 0; i < n; ++i)
-		if (t.nodes[i].link_r >= 0) inner_id[i] = (int32_t)n_inner++;
+	const char *order_env = getenv("RTGI_HIP_NODE_ORDER");
+	if (order_env && std::string(order_env) == "dfs") {
+		for (uint32_t i = 0; i < n; ++i)
+			if (t.nodes[i].link_r >= 0) inner_id[i] = (int32_t)n_inner++;
+	} else {
+		std::vector<uint32_t> queue;
+		queue.reserve(n);
+		if (t.nodes[t.root].link_r >= 0) queue.push_back(t.root);
+		for (size_t head = 0; head < queue.size(); ++head) {
+			const rtgi_node56 &nd = t.nodes[queue[head]];
+			inner_id[queue[head]] = (int32_t)n_inner++;
+			if (t.nodes[nd.link_l].link_r >= 0) queue.push_back((uint32_t)nd.link_l);
+			if (t.nodes[nd.link_r].link_r >= 0) queue.push_back((uint32_t)nd.link_r);
+		}
+	}
 	auto ref_of = [&](uint32_t node) -> int32_t {
 		const rtgi_node56 &nd = t.nodes[node];
 		if (nd.link_r >= 0) return inner_id[node];
@@ -401,12 +417,12 @@ void flatten_tree(const HostTree &t, const SceneView &scene, int layout, FlatTre
 		if (nd.link_r < 0) continue;
 		float *g = out.nodes.data() + (size_t)inner_id[i] * 16;
 		int32_t rl = ref_of((uint32_t)nd.link_l), rr = ref_of((uint32_t)nd.link_r);
-		memcpy(g + 0, nd.box_l, 12);
-		memcpy(g + 3, &rl, 4);
-		memcpy(g + 4, nd.box_l + 3, 12);
-		memcpy(g + 7, &rr, 4);
-		memcpy(g + 8, nd.box_r, 12);
-		memcpy(g + 12, nd.box_r + 3, 12);
+		// child boxes interleaved (l, r) per coordinate: one packed instruction serves both children
+		const float *L = nd.box_l, *R = nd.box_r;  // min.xyz, max.xyz
+		const float packed[12] = {L[0], R[0], L[1], R[1], L[2], R[2], L[3], R[3], L[4], R[4], L[5], R[5]};
+		memcpy(g, packed, sizeof(packed));
+		memcpy(g + 12, &rl, 4);
+		memcpy(g + 13, &rr, 4);
 	}
 	out.tris.assign((size_t)out.n_slots * 12, 0.0f);
 	for (uint32_t s = 0; s < out.n_slots; ++s) {

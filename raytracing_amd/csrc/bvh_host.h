@@ -38,9 +38,9 @@ struct HostTree {
 	uint32_t depth = 0;  // deepest leaf, root = 0
 };
 
-// GPU form. Inner nodes only, 64 bytes each as four float4:
-//   [0] = left.min.xyz,  bits(link_l)    [1] = left.max.xyz,  bits(link_r)
-//   [2] = right.min.xyz, 0               [3] = right.max.xyz, 0
+// GPU form. Inner nodes only, 64 bytes each as four float4, the two child boxes interleaved per coordinate:
+//   [0] = l.min.x r.min.x l.min.y r.min.y    [1] = l.min.z r.min.z l.max.x r.max.x
+//   [2] = l.max.y r.max.y l.max.z r.max.z    [3] = bits(link_l) bits(link_r) 0 0
 // A link >= 0 is an inner-node index; a link < 0 is ~slot of the first triangle of a leaf.
 // Triangles, 48 bytes each as three float4, in leaf order:
 //   [0] = A.xyz, bits(id reported in rtgi_hit.ref)

@@ -1,0 +1,313 @@
+// trace_kernel.h -- the gfx950 traversal kernel (device code only; included by rtgi_hip.hip).
+//
+// closest_hit / any_hit of rt/bbvh-base/bvh2.cpp:415-501, ray by ray in the reference's order: nearer child
+// first (the right one on equal distances), a child is entered only if its slab test passes and, for
+// closest_hit, its entry distance is below the closest t so far; triangles by Cramer's rule in the operation
+// order of libgi/intersect.h:43-57; slab test of libgi/intersect.h:204-236.
+//
+// One ray per lane, wave64, persistent workgroups. The kernel is bound by instruction issue, not by memory
+// (halving the resident waves costs a few percent), so the design goal is few wave-instructions per useful
+// lane-step:
+//  * a wave refills finished lanes from a global ray counter instead of waiting for its slowest ray;
+//  * lanes that reach a leaf wait until a handful have gathered, then the (long) triangle code runs for all
+//    of them at once; per ray the order of node visits and triangle tests is unchanged;
+//  * node records interleave the two child boxes (l.x r.x l.y r.y ...) so that one packed instruction
+//    subtracts / multiplies for both children;
+//  * loads go through buffer descriptors: a 32-bit per-lane offset instead of 64-bit address arithmetic,
+//    and an out-of-range index reads zeros instead of faulting;
+//  * the pending-node stack keeps its top in a register and the rest in LDS as [level][lane] (any mix of
+//    depths is conflict-free); trees deeper than STACK_LDS use the DEEP variant, which continues the stack
+//    in a global area sized from the tree depth, so the stack cannot overflow.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdint>
+#include <type_traits>
+
+namespace rtgi_dev {
+
+constexpr int BLOCK = 256;      // 4 waves per workgroup
+constexpr int STACK_LDS = 24;   // pending nodes per lane held in LDS (beyond the one in a register)
+constexpr int COUNTER_STRIDE = 32;
+constexpr int32_t IDLE = INT32_MIN;  // lane has no ray; leaf references are ~slot with slot < 2^30
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct TraceArgs {
+	const void *nodes;      // 64 B per inner node, see pack_node() in bvh_host.cpp
+	const void *tris;       // 48 B per leaf-order slot
+	const float4 *rays;     // 32 B per ray: o.xyz d.x | d.yz t_min t_max
+	float4 *hits;           // closest_hit output
+	uint8_t *occluded;      // any_hit output
+	uint32_t *counts;       // optional: 2 per ray
+	int32_t *spill;         // DEEP only: [level - STACK_LDS][global lane]
+	uint32_t *ray_counter;  // n_segments counters, COUNTER_STRIDE words apart (one cache line each)
+	uint32_t n_rays;
+	uint32_t n_segments;    // the ray range is cut into this many contiguous segments (1 or 8)
+	uint32_t node_bytes, tri_bytes;
+	uint32_t spill_stride;  // = gridDim.x * BLOCK
+	int32_t root_ref;
+	int32_t refill_min;     // refill a wave once this many lanes are idle
+	int32_t leaf_min;       // leave the inner-node loop once this many lanes have left it
+};
+
+// Single-instruction min / max for values that cannot be NaN. (fminf/fmaxf would first canonicalise every
+// operand with an extra v_max_f32 x, x because the compiler cannot see that.)
+__device__ __forceinline__ float vmin(float a, float b) {
+	float r;
+	asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+}
+__device__ __forceinline__ float vmax(float a, float b) {
+	float r;
+	asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+}
+__device__ __forceinline__ float vmin3(float a, float b, float c) {
+	float r;
+	asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+	return r;
+}
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+	float r;
+	asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+	return r;
+}
+
+__device__ __forceinline__ float next_up(float x) {
+	// smallest float greater than x, for finite or -inf x; +inf stays
+	uint32_t b = __float_as_uint(x);
+	if (x == 0.0f) return __uint_as_float(1u);
+	if (x != x || b == 0x7f800000u) return x;
+	return __uint_as_float((b & 0x80000000u) ? b - 1u : b + 1u);
+}
+
+template <bool ANY, bool COUNT, bool DEEP>
+__global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
+	__shared__ int32_t s_stack[STACK_LDS][BLOCK];
+	const int tid = threadIdx.x;
+	const int lane = tid & 63;
+	const uint32_t gl = blockIdx.x * BLOCK + tid;
+
+	const __amdgpu_buffer_rsrc_t node_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.nodes), 0, (int)a.node_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t tri_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.tris), 0, (int)a.tri_bytes, 0x00020000);
+
+	float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, ix = 0, iy = 0, iz = 0, t_min = 0, t_max = 0;
+	float lim = 0;       // plain rays: entry distances below this pass "t1 <= t_max (&& t1 < closest t)"
+	float lim0 = 0;      // next_up(t_max)
+	float best_t = FLT_MAX, best_b = 0.0f, best_g = 0.0f;
+	uint32_t best_ref = 0;
+	uint32_t ray_id = 0;
+	uint32_t n_inner = 0, n_tri = 0;
+	int32_t cur = IDLE;
+	int sp = 0;          // pending entries in memory (the next node to visit is `cur`, in a register)
+	bool plain = true;   // no NaN can arise in this ray's slab tests
+	bool more = true;    // wave-uniform: some segment may still have rays
+	// Each XCD has its own L2. Waves of one XCD draw rays from the same contiguous part of the batch, so that
+	// an L2 sees neighbouring rays (callers hand rays over in image or sorted order); a wave whose segment is
+	// used up helps with the next one. Placement affects speed only.
+	uint32_t seg = (__builtin_amdgcn_s_getreg(6164) & 15u) % a.n_segments;  // HW_REG_XCC_ID, bits 3:0
+	uint32_t segs_done = 0;
+
+	auto push = [&](int32_t v) {
+		if (!DEEP || sp < STACK_LDS)
+			s_stack[sp][tid] = v;
+		else
+			a.spill[(size_t)(sp - STACK_LDS) * a.spill_stride + gl] = v;
+		++sp;
+	};
+	auto pop = [&]() -> int32_t {
+		--sp;
+		if (!DEEP || sp < STACK_LDS) return s_stack[sp][tid];
+		return a.spill[(size_t)(sp - STACK_LDS) * a.spill_stride + gl];
+	};
+	auto finish = [&]() {
+		if (ANY)
+			a.occluded[ray_id] = best_ref ? 1 : 0;
+		else
+			a.hits[ray_id] = make_float4(best_t, best_b, best_g, __uint_as_float(best_ref));
+		if (COUNT) {
+			a.counts[2 * (size_t)ray_id] = n_inner;
+			a.counts[2 * (size_t)ray_id + 1] = n_tri;
+		}
+		cur = IDLE;
+	};
+	auto advance = [&]() {  // next pending node, or the ray is done
+		if (sp == 0)
+			finish();
+		else
+			cur = pop();
+	};
+
+	for (;;) {
+		// ---- hand new rays to idle lanes --------------------------------------------------------------
+		const unsigned long long idle = __ballot(cur == IDLE);
+		if (more && __popcll(idle) >= a.refill_min) {
+			const uint32_t want = (uint32_t)__popcll(idle);
+			const int leader = (int)__ffsll((long long)idle) - 1;
+			uint32_t first = 0, avail = 0;
+			for (;;) {  // draw from this wave's segment; when it is used up, move on to the next one
+				const uint32_t seg_lo = (uint32_t)((uint64_t)a.n_rays * seg / a.n_segments);
+				const uint32_t seg_len = (uint32_t)((uint64_t)a.n_rays * (seg + 1) / a.n_segments) - seg_lo;
+				uint32_t base = 0;
+				if (lane == leader) base = atomicAdd(a.ray_counter + seg * COUNTER_STRIDE, want);
+				base = __shfl(base, leader);
+				if (base < seg_len) {
+					first = seg_lo + base;
+					avail = min(want, seg_len - base);
+					break;
+				}
+				if (++segs_done == a.n_segments) {
+					more = false;
+					break;
+				}
+				seg = seg + 1 == a.n_segments ? 0 : seg + 1;
+			}
+			const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+			if (cur == IDLE && rank < avail) {
+				const uint32_t mine = first + rank;
+				const float4 q0 = a.rays[2 * (size_t)mine], q1 = a.rays[2 * (size_t)mine + 1];
+				ox = q0.x, oy = q0.y, oz = q0.z;
+				dx = q0.w, dy = q1.x, dz = q1.y;
+				t_min = q1.z, t_max = q1.w;
+				ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;  // ray::ray, libgi/rt.h:24
+				auto usable = [](float v) { return __builtin_isfinite(v) && v != 0.0f; };
+				plain = usable(ix) && usable(iy) && usable(iz) && __builtin_isfinite(ox) && __builtin_isfinite(oy) &&
+				        __builtin_isfinite(oz) && t_min == t_min && t_max == t_max && t_max != __builtin_inff();
+				lim0 = next_up(t_max);
+				lim = ANY ? lim0 : __builtin_fminf(FLT_MAX, lim0);
+				ray_id = mine;
+				best_t = FLT_MAX, best_b = 0.0f, best_g = 0.0f, best_ref = 0;
+				n_inner = n_tri = 0;
+				cur = a.root_ref;
+				sp = 0;
+			}
+		}
+		const unsigned long long busy = __ballot(cur != IDLE);
+		if (busy == 0) {
+			if (!more) break;
+			continue;
+		}
+		const bool wave_plain = __ballot(cur != IDLE && !plain) == 0;
+		const int keep_going = max(0, (int)__popcll(busy) - a.leaf_min);
+
+		// ---- inner nodes: every lane standing on an inner node takes one step per iteration; the loop ends
+		// once leaf_min lanes have left it (reached a leaf or finished their ray), or nobody is left --------
+		auto inner_phase = [&](auto plain_tag) {
+			constexpr bool PLAIN = decltype(plain_tag)::value;
+			for (;;) {
+				const bool at_inner = cur >= 0;
+				if ((int)__popcll(__ballot(at_inner)) <= keep_going) break;
+				if (at_inner) {
+					const int voff = cur << 6;
+					const u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(node_rsrc, voff, 0, 0);
+					const u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(node_rsrc, voff + 16, 0, 0);
+					const u32x4 q2 = __builtin_amdgcn_raw_buffer_load_b128(node_rsrc, voff + 32, 0, 0);
+					const u32x4 q3 = __builtin_amdgcn_raw_buffer_load_b128(node_rsrc, voff + 48, 0, 0);
+					if (COUNT) ++n_inner;
+					auto pair = [](uint32_t u, uint32_t v) { return f32x2{__uint_as_float(u), __uint_as_float(v)}; };
+					// .x = left child, .y = right child; (box - o) * id as in libgi/intersect.h:210-221
+					const f32x2 ax = (pair(q0.x, q0.y) - f32x2{ox, ox}) * f32x2{ix, ix};
+					const f32x2 ay = (pair(q0.z, q0.w) - f32x2{oy, oy}) * f32x2{iy, iy};
+					const f32x2 az = (pair(q1.x, q1.y) - f32x2{oz, oz}) * f32x2{iz, iz};
+					const f32x2 bx = (pair(q1.z, q1.w) - f32x2{ox, ox}) * f32x2{ix, ix};
+					const f32x2 by = (pair(q2.x, q2.y) - f32x2{oy, oy}) * f32x2{iy, iy};
+					const f32x2 bz = (pair(q2.z, q2.w) - f32x2{oz, oz}) * f32x2{iz, iz};
+					const int32_t link_l = (int32_t)q3.x, link_r = (int32_t)q3.y;
+					float dl, dr;
+					bool hl, hr;
+					if (PLAIN) {
+						// no NaN possible: the selects of intersect.h:212-228 are exact min / max, and
+						// !(t1 > t2) && !(t2 < t_min) && !(t1 > t_max) [&& t1 < closest t] folds into two compares
+						dl = vmax3(vmin(ax.x, bx.x), vmin(ay.x, by.x), vmin(az.x, bz.x));
+						dr = vmax3(vmin(ax.y, bx.y), vmin(ay.y, by.y), vmin(az.y, bz.y));
+						const float fl = vmin3(vmax(ax.x, bx.x), vmax(ay.x, by.x), vmax(az.x, bz.x));
+						const float fr = vmin3(vmax(ax.y, bx.y), vmax(ay.y, by.y), vmax(az.y, bz.y));
+						hl = (vmax(dl, t_min) <= fl) && (dl < lim);
+						hr = (vmax(dr, t_min) <= fr) && (dr < lim);
+					} else {
+						auto slab = [&](float a_x, float b_x, float a_y, float b_y, float a_z, float b_z, float &entry) {
+							float nx = (a_x < b_x) ? a_x : b_x, fx = (b_x < a_x) ? a_x : b_x;
+							float ny = (a_y < b_y) ? a_y : b_y, fy = (b_y < a_y) ? a_y : b_y;
+							float nz = (a_z < b_z) ? a_z : b_z, fz = (b_z < a_z) ? a_z : b_z;
+							float t1 = (nx < ny) ? ny : nx;
+							t1 = (nz < t1) ? t1 : nz;
+							float t2 = (fx < fy) ? fx : fy;
+							t2 = (fz < t2) ? fz : t2;
+							entry = t1;
+							bool hit = !(t1 > t2) && !(t2 < t_min) && !(t1 > t_max);
+							if (!ANY) hit = hit && t1 < best_t;  // bvh2.cpp:432-433; not in any_hit (:476-477)
+							return hit;
+						};
+						hl = slab(ax.x, bx.x, ay.x, by.x, az.x, bz.x, dl);
+						hr = slab(ax.y, bx.y, ay.y, by.y, az.y, bz.y, dr);
+					}
+					// bvh2.cpp:434-446: both hit -> nearer first, the right child on a tie, the other one pending
+					const bool left_first = hl && ((dl < dr) || !hr);
+					const int32_t first = left_first ? link_l : link_r;
+					const int32_t second = left_first ? link_r : link_l;
+					if (hl && hr) push(second);
+					if (hl || hr)
+						cur = first;
+					else
+						advance();
+				}
+			}
+		};
+		if (wave_plain)
+			inner_phase(std::true_type{});
+		else
+			inner_phase(std::false_type{});
+
+		// ---- leaves: all triangles of the leaf, in slot order ---------------------------------------------
+		if (cur < 0 && cur != IDLE) {
+			int voff = (int)(~cur) * 48;
+			bool done = false;
+			for (;;) {
+				const u32x4 t0 = __builtin_amdgcn_raw_buffer_load_b128(tri_rsrc, voff, 0, 0);
+				const u32x4 t1 = __builtin_amdgcn_raw_buffer_load_b128(tri_rsrc, voff + 16, 0, 0);
+				const u32x4 t2 = __builtin_amdgcn_raw_buffer_load_b128(tri_rsrc, voff + 32, 0, 0);
+				if (COUNT) ++n_tri;
+				// libgi/intersect.h:26-57, letters as there; a..f were subtracted on the host (same rounding)
+				const float ea = __uint_as_float(t1.x), eb = __uint_as_float(t1.y), ec = __uint_as_float(t1.z);
+				const float ed = __uint_as_float(t2.x), ee = __uint_as_float(t2.y), ef = __uint_as_float(t2.z);
+				const float g = dx, h = dy, i = dz;
+				const float j = __uint_as_float(t0.x) - ox, k = __uint_as_float(t0.y) - oy, l = __uint_as_float(t0.z) - oz;
+				float c1 = ee * i - h * ef;
+				float c2 = g * ef - ed * i;
+				float c3 = ed * h - ee * g;
+				const float M = ea * c1 + eb * c2 + ec * c3;
+				float beta = j * c1 + k * c2 + l * c3;
+				c1 = ea * k - j * eb;
+				c2 = j * ec - ea * l;
+				c3 = eb * l - k * ec;
+				float gamma = i * c1 + h * c2 + g * c3;
+				float tt = -(ef * c1 + ee * c2 + ed * c3);
+				beta /= M;
+				gamma /= M;
+				tt /= M;
+				if (tt > t_min && tt < t_max && beta > 0 && gamma > 0 && beta + gamma <= 1) {
+					if (ANY) {
+						best_ref = 1;
+						done = true;
+					} else if (tt < best_t) {
+						best_t = tt, best_b = beta, best_g = gamma;
+						best_ref = t0.w;
+						lim = __builtin_fminf(best_t, lim0);
+					}
+				}
+				if (done || t1.w) break;
+				voff += 48;
+			}
+			if (done)
+				finish();
+			else
+				advance();
+		}
+	}
+}
+
+}  // namespace rtgi_dev

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtgi_hip.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("RTGI_HIP_LIB", "librtgi_hip.so"))
 
 RAY_DTYPE = np.dtype([("o", "<f4", (3,)), ("d", "<f4", (3,)), ("t_min", "<f4"), ("t_max", "<f4")])
 HIT_DTYPE = np.dtype([("t", "<f4"), ("beta", "<f4"), ("gamma", "<f4"), ("ref", "<u4")])

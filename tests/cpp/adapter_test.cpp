@@ -1,0 +1,152 @@
+// Exercises include/rtgi_hip_tracer.hpp the way the renderer would: through ray_tracer* / dynamic_cast
+// (libgi/scene.cpp:207-212), script-style "bvh ..." commands, build(scene*), compute_closest_hit() /
+// compute_any_hit() and the per-ray closest_hit() / any_hit(). Results are checked against the CPU oracle.
+//   adapter_test host   -> no GPU needed: build + interprete + triangle permutation semantics
+//   adapter_test gpu    -> full run on device 0
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <random>
+
+#include "rtgi_hip_tracer.hpp"
+
+extern "C" {  // CPU oracle (test infrastructure), oracle/rtgi_oracle.cpp
+void *orc_bbvh_build(const float *pos, uint32_t nv, const uint32_t *tri, uint32_t nt, int layout, int esc, int split, int planes, int max_tris);
+void orc_bbvh_destroy(void *b);
+uint32_t orc_bbvh_num_nodes(void *b);
+void orc_bbvh_copy_nodes(void *b, void *out56);
+void orc_bbvh_copy_triangles(void *b, uint32_t *tri);
+void orc_bbvh_closest_hit(void *b, const float *rays8, uint32_t n, void *hits, uint32_t *counts, uint32_t *max_stack, int threads);
+void orc_bbvh_any_hit(void *b, const float *rays8, uint32_t n, uint8_t *out, uint32_t *counts, int threads);
+}
+
+using namespace rtgi_hip;
+
+static int failures = 0;
+#define EXPECT(cond)                                                  \
+	do {                                                              \
+		if (!(cond)) {                                                \
+			printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond);    \
+			++failures;                                               \
+		}                                                             \
+	} while (0)
+
+static void make_soup(rtgi_hip::scene &s, int n, unsigned seed) {
+	std::mt19937 rng(seed);
+	std::uniform_real_distribution<float> centre(-10.f, 10.f), offset(-0.3f, 0.3f);
+	for (int i = 0; i < n; ++i) {
+		vec3 c(centre(rng), centre(rng), centre(rng));
+		for (int k = 0; k < 3; ++k) {
+			vertex v;
+			v.pos = vec3(c.x + offset(rng), c.y + offset(rng), c.z + offset(rng));
+			v.norm = vec3(0, 1, 0);
+			s.vertices.push_back(v);
+		}
+		s.triangles.push_back(triangle{(uint32_t)(3 * i), (uint32_t)(3 * i + 1), (uint32_t)(3 * i + 2), 0u});
+	}
+}
+
+int main(int argc, char **argv) {
+	const bool gpu = argc > 1 && std::string(argv[1]) == "gpu";
+	const int device = gpu ? 0 : -1;
+	const int n_tris = 3000, n_rays = 20000;
+
+	rtgi_hip::scene sc;
+	make_soup(sc, n_tris, 7);
+	std::vector<float> pos(sc.vertices.size() * 3);
+	std::vector<uint32_t> tri(sc.triangles.size() * 3);
+	for (size_t i = 0; i < sc.vertices.size(); ++i) {
+		pos[3 * i] = sc.vertices[i].pos.x, pos[3 * i + 1] = sc.vertices[i].pos.y, pos[3 * i + 2] = sc.vertices[i].pos.z;
+	}
+	for (size_t i = 0; i < sc.triangles.size(); ++i) {
+		tri[3 * i] = sc.triangles[i].a, tri[3 * i + 1] = sc.triangles[i].b, tri[3 * i + 2] = sc.triangles[i].c;
+	}
+
+	// "raytracer hip" + "bvh sah 8" + "commit", through the base-class interface
+	std::unique_ptr<ray_tracer> rt(new hip_bvh_batch_tracer(/*indexed*/ false, /*esc*/ false, device));
+	auto *batch = dynamic_cast<wf::batch_ray_tracer *>(rt.get());
+	EXPECT(batch != nullptr);
+	EXPECT(dynamic_cast<individual_ray_tracer *>(rt.get()) == nullptr);
+	std::istringstream cmd("sah 8"), bad("sah"), other("select pod");
+	EXPECT(rt->interprete("bvh", cmd));
+	EXPECT(rt->interprete("bvh", bad));          // malformed: reported on stderr, still consumed
+	EXPECT(!rt->interprete("material", other));  // not a tracer command
+	rt->build(&sc);
+
+	// the oracle with the same settings; the flat layout must have permuted scene.triangles identically
+	void *o = orc_bbvh_build(pos.data(), (uint32_t)sc.vertices.size(), tri.data(), (uint32_t)sc.triangles.size(), 0, 0, 2, 8, 1);
+	EXPECT(o != nullptr);
+	std::vector<uint32_t> otri(tri.size());
+	orc_bbvh_copy_triangles(o, otri.data());
+	bool same_perm = true;
+	for (size_t i = 0; i < sc.triangles.size(); ++i)
+		same_perm = same_perm && sc.triangles[i].a == otri[3 * i] && sc.triangles[i].b == otri[3 * i + 1] && sc.triangles[i].c == otri[3 * i + 2];
+	EXPECT(same_perm);
+	auto *hb = static_cast<hip_bvh_batch_tracer *>(rt.get());
+	std::vector<rtgi_node56> nodes(rtgi_hip_num_nodes(hb->core.handle())), onodes(orc_bbvh_num_nodes(o));
+	EXPECT(nodes.size() == onodes.size());
+	rtgi_hip_get_nodes(hb->core.handle(), nodes.data());
+	orc_bbvh_copy_nodes(o, onodes.data());
+	EXPECT(nodes.size() == onodes.size() && memcmp(nodes.data(), onodes.data(), nodes.size() * sizeof(rtgi_node56)) == 0);
+
+	if (gpu) {
+		std::mt19937 rng(11);
+		std::uniform_real_distribution<float> u(-10.f, 10.f), dir(-1.f, 1.f);
+		std::vector<ray> rays;
+		std::vector<float> rays8;
+		for (int i = 0; i < n_rays; ++i) {
+			vec3 d(dir(rng), dir(rng), dir(rng));
+			float len = std::sqrt(d.x * d.x + d.y * d.y + d.z * d.z);
+			ray r(vec3(u(rng), u(rng), u(rng)), vec3(d.x / len, d.y / len, d.z / len));
+			if (i % 3 == 0) r.length_exclusive(4.0f);
+			rays.push_back(r);
+			const float f[8] = {r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z, r.t_min, r.t_max};
+			rays8.insert(rays8.end(), f, f + 8);
+		}
+		std::vector<triangle_intersection> got(n_rays), want(n_rays);
+		std::vector<uint8_t> want_any(n_rays);
+		orc_bbvh_closest_hit(o, rays8.data(), n_rays, want.data(), nullptr, nullptr, 0);
+		orc_bbvh_any_hit(o, rays8.data(), n_rays, want_any.data(), nullptr, 0);
+		hb->set_batch(rays.data(), got.data(), rays.size());
+		batch->compute_closest_hit();
+		int hits = 0;
+		bool same = true;
+		for (int i = 0; i < n_rays; ++i) {
+			hits += got[i].valid();
+			same = same && memcmp(&got[i].t, &want[i].t, 4) == 0 && got[i].ref == want[i].ref;
+			if (want[i].valid()) same = same && memcmp(&got[i].beta, &want[i].beta, 8) == 0;
+		}
+		EXPECT(same);
+		EXPECT(hits > n_rays / 20);
+		batch->compute_any_hit();
+		bool same_any = true;
+		for (int i = 0; i < n_rays; ++i) same_any = same_any && !got[i].valid() && got[i].ref == (unsigned)want_any[i];
+		EXPECT(same_any);
+
+		// per-ray interface on a tracer of its own (indexed layout: ids are original ids, scene untouched)
+		rtgi_hip::scene sc2;
+		make_soup(sc2, n_tris, 7);
+		hip_bvh_individual_tracer single(/*indexed*/ true);
+		individual_ray_tracer *irt = &single;
+		irt->build(&sc2);
+		EXPECT(sc2.triangles[5].a == 15);
+		void *o2 = orc_bbvh_build(pos.data(), (uint32_t)sc2.vertices.size(), tri.data(), (uint32_t)sc2.triangles.size(), 1, 0, 0, 0, 1);
+		std::vector<triangle_intersection> w2(64);
+		std::vector<uint8_t> a2(64);
+		orc_bbvh_closest_hit(o2, rays8.data(), 64, w2.data(), nullptr, nullptr, 1);
+		orc_bbvh_any_hit(o2, rays8.data(), 64, a2.data(), nullptr, 1);
+		bool same_single = true;
+		for (int i = 0; i < 64; ++i) {
+			triangle_intersection is = irt->closest_hit(rays[i]);
+			same_single = same_single && memcmp(&is.t, &w2[i].t, 4) == 0 && is.ref == w2[i].ref;
+			same_single = same_single && irt->any_hit(rays[i]) == (a2[i] != 0);
+		}
+		EXPECT(same_single);
+		orc_bbvh_destroy(o2);
+		printf("gpu: %d rays, %d hits\n", n_rays, hits);
+	}
+	orc_bbvh_destroy(o);
+	printf(failures ? "adapter_test: %d FAILURES\n" : "adapter_test: OK\n", failures);
+	return failures ? 1 : 0;
+}
