@@ -64,19 +64,21 @@ def build_workload(args, rank, device):
     tri_original = tri
     if args.layout == "flat":  # commit_shuffled_triangles: hit ids index the permuted list
         tri = tri[t.triangle_order()]
-    # sample index = rank: jittered camera rays, then one diffuse bounce
-    jitter = np.stack([wavefront.uniform01(np.arange(args.width * args.height), 100, rank) - 0.5,
-                       wavefront.uniform01(np.arange(args.width * args.height), 101, rank) - 0.5], 1)
-    primary = wavefront.camera_rays(cam_dir / np.linalg.norm(cam_dir), cam_pos, cam_up, 65.0, args.width, args.height,
-                                    jitter.reshape(args.height, args.width, 2).astype(np.float32))
-    d_primary = torch.from_numpy(primary).to("cuda:%d" % device)
-    d_hits = torch.empty((len(primary), 4), dtype=torch.float32, device=d_primary.device)
+    # sample index = rank: jittered camera rays, closest_hit, then one diffuse bounce -- all on the GPU
+    dev = "cuda:%d" % device
+    npix = args.width * args.height
+    jitter = np.stack([wavefront.uniform01(np.arange(npix), 100, rank) - 0.5,
+                       wavefront.uniform01(np.arange(npix), 101, rank) - 0.5], 1).astype(np.float32)
+    cam_dir = np.asarray(cam_dir, np.float32) / np.float32(np.linalg.norm(cam_dir))
+    d_primary = t.camera_rays_device(cam_dir, cam_pos, cam_up, 65.0, args.width, args.height,
+                                     d_offsets=torch.from_numpy(jitter).to(dev))
+    d_hits = torch.empty((npix, 4), dtype=torch.float32, device=dev)
     t.closest_hit_device(d_primary, d_hits)
+    d_bounce, _ = t.bounce_rays_device(d_primary, d_hits, seed=rank, bounce=1)
     torch.cuda.synchronize(device)
-    hits = d_hits.cpu().numpy().view(tracer.HIT_DTYPE).reshape(-1)
-    bounce, _ = wavefront.bounce_rays(pos, tri, primary, hits, seed=rank, bounce=1)
-    return dict(tracer=t, pos=pos, tri=tri, tri_original=tri_original, primary=primary, bounce=bounce, build_s=build_s,
-                primary_hit_rate=float((hits["t"] != tracer.FLT_MAX).mean()))
+    hit_rate = float((d_hits[:, 0] != tracer.FLT_MAX).float().mean().item())
+    return dict(tracer=t, pos=pos, tri=tri, tri_original=tri_original, bounce=d_bounce.contiguous().cpu().numpy(),
+                build_s=build_s, primary_hit_rate=hit_rate)
 
 
 def algorithmic_bytes(t, d_rays, layout):

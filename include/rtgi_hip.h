@@ -125,6 +125,36 @@ int rtgi_hip_closest_hit_device(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint
 int rtgi_hip_any_hit_device(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint32_t n, uint8_t *d_occluded,
                             uint32_t *d_counts, void *stream);
 
+/* ---- ray populations around the tracer, produced on the GPU (the wavefront pipeline's other stages) ---- */
+
+/* struct camera, libgi/camera.h:7-25 (near_w / near_h are derived from fovy, w, h as update_frustum does). */
+typedef struct rtgi_camera {
+	float dir[3], pos[3], up[3];
+	float fovy;
+	int32_t w, h;
+} rtgi_camera;
+
+/* batch_cam_ray_setup_cpu::run(), libgi/wavefront-rt.h:90-102: d_rays[y*w+x] = cam_ray(cam, x, y, offset)
+ * (libgi/camera.cpp:11-22). d_offsets: w*h pairs of sub-pixel offsets (what the caller's rng would supply,
+ * uniform in [-0.5, 0.5)), or NULL for pixel centres. Needs no build(). */
+int rtgi_hip_camera_rays_device(rtgi_hip_tracer *h, const rtgi_camera *cam, const float *d_offsets, rtgi_ray *d_rays,
+                                void *stream);
+
+/* Shadow rays of local_illumination::sample_pixel, gi/primary-hit.cpp:43-50, one slot per hit record: origin
+ * diff_geom::x (libgi/rt.cpp:9), direction towards light_pos, t_max = distance - 1e-4 (ray::length_exclusive).
+ * Slots whose hit record is a miss get an empty ray (t_max < t_min), which any_hit reports as not occluded. */
+int rtgi_hip_shadow_rays_device(rtgi_hip_tracer *h, const rtgi_hit *d_hits, uint32_t n, const float light_pos[3],
+                                rtgi_ray *d_shadow, void *stream);
+
+/* One diffuse bounce (no counterpart in the reference, which has no path tracer): for every ray that hit
+ * something, a ray from the hit point into a cosine-weighted direction about the geometric normal facing the
+ * incoming ray, random numbers keyed by (ray index, bounce, seed). The new rays are written densely to d_out in
+ * the order of their parent rays (wave ballot/popcount compaction + one scan); d_parent (optional) receives
+ * each one's parent index, *d_count their number. d_out needs room for n rays. */
+int rtgi_hip_bounce_rays_device(rtgi_hip_tracer *h, const rtgi_ray *d_rays, const rtgi_hit *d_hits, uint32_t n,
+                                uint32_t seed, uint32_t bounce, rtgi_ray *d_out, uint32_t *d_parent, uint32_t *d_count,
+                                void *stream);
+
 /* Text of the last error on this handle (h may be NULL: last error of a failed create). */
 const char *rtgi_hip_last_error(const rtgi_hip_tracer *h);
 

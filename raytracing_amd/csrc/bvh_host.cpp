@@ -438,6 +438,13 @@ void flatten_tree(const HostTree &t, const SceneView &scene, int layout, FlatTre
 		}
 		memcpy(g + 3, &id, 4);
 	}
+	// corner positions by reported id, for the stages that turn hits into new rays
+	const uint32_t n_ids = (layout == RTGI_LAYOUT_FLAT) ? out.n_slots : scene.n_triangles;
+	out.corners.assign((size_t)n_ids * 12, 0.0f);
+	for (uint32_t id = 0; id < n_ids; ++id) {
+		const uint32_t *v = scene.tri(layout == RTGI_LAYOUT_FLAT ? t.order[id] : id);
+		for (int c = 0; c < 3; ++c) memcpy(out.corners.data() + (size_t)id * 12 + 4 * c, scene.pos(v[c]), 12);
+	}
 	for (uint32_t i = 0; i < n; ++i) {
 		const rtgi_node56 &nd = t.nodes[i];
 		if (nd.link_r >= 0) continue;

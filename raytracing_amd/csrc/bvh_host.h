@@ -49,6 +49,7 @@ struct HostTree {
 struct FlatTree {
 	std::vector<float> nodes;  // 16 floats per inner node
 	std::vector<float> tris;   // 12 floats per slot
+	std::vector<float> corners;  // 12 floats (A, B, C as float4) per id that a hit can report
 	int32_t root_ref = 0;
 	uint32_t n_inner = 0, n_slots = 0;
 	uint32_t depth = 0;

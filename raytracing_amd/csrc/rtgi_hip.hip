@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -15,6 +16,7 @@
 #include "bvh_host.h"
 #include "rtgi_hip.h"
 #include "trace_kernel.h"
+#include "wavefront_kernels.h"
 
 using rtgi_dev::BLOCK;
 using rtgi_dev::STACK_LDS;
@@ -39,6 +41,9 @@ struct rtgi_hip_tracer {
 
 	void *d_nodes = nullptr;
 	void *d_tris = nullptr;
+	float4 *d_corners = nullptr;  // triangle corners by reported id
+	uint32_t *d_wave_counts = nullptr;
+	size_t wave_counts_cap = 0;
 	uint32_t node_bytes = 0, tri_bytes = 0;
 	int refill_min = 16, leaf_min = 8;
 	uint32_t n_segments = 8;
@@ -70,6 +75,8 @@ void free_device_tree(rtgi_hip_tracer *h) {
 	if (h->d_nodes) (void)hipFree(h->d_nodes);
 	if (h->d_tris) (void)hipFree(h->d_tris);
 	if (h->d_spill) (void)hipFree(h->d_spill);
+	if (h->d_corners) (void)hipFree(h->d_corners);
+	h->d_corners = nullptr;
 	h->d_nodes = h->d_tris = nullptr;
 	h->d_spill = nullptr;
 	h->built = false;
@@ -105,6 +112,8 @@ int upload(rtgi_hip_tracer *h, const rtgi::SceneView &scene) {
 	if (const char *e = getenv("RTGI_HIP_LEAF_MIN")) h->leaf_min = std::max(1, std::min(64, atoi(e)));
 	if (!flat.nodes.empty()) HIP_TRY(h, hipMemcpy(h->d_nodes, flat.nodes.data(), flat.nodes.size() * sizeof(float), hipMemcpyHostToDevice));
 	HIP_TRY(h, hipMemcpy(h->d_tris, flat.tris.data(), flat.tris.size() * sizeof(float), hipMemcpyHostToDevice));
+	HIP_TRY(h, hipMalloc((void **)&h->d_corners, std::max<size_t>(flat.corners.size() * sizeof(float), 48)));
+	HIP_TRY(h, hipMemcpy(h->d_corners, flat.corners.data(), flat.corners.size() * sizeof(float), hipMemcpyHostToDevice));
 	if (h->spill_levels)
 		HIP_TRY(h, hipMalloc((void **)&h->d_spill, (size_t)h->spill_levels * h->grid_blocks * BLOCK * sizeof(int32_t)));
 	if (!h->d_counter) HIP_TRY(h, hipMalloc((void **)&h->d_counter, 8 * rtgi_dev::COUNTER_STRIDE * sizeof(uint32_t)));
@@ -234,6 +243,7 @@ void rtgi_hip_destroy(rtgi_hip_tracer *h) {
 	if (h->d_counter) (void)hipFree(h->d_counter);
 	if (h->d_stage_rays) (void)hipFree(h->d_stage_rays);
 	if (h->d_stage_out) (void)hipFree(h->d_stage_out);
+	if (h->d_wave_counts) (void)hipFree(h->d_wave_counts);
 	delete h;
 }
 
@@ -380,6 +390,92 @@ int rtgi_hip_closest_hit_device(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint
 int rtgi_hip_any_hit_device(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint32_t n, uint8_t *d_occluded,
                             uint32_t *d_counts, void *stream) {
 	return launch<true>(h, d_rays, n, d_occluded, d_counts, (hipStream_t)stream);
+}
+
+int rtgi_hip_camera_rays_device(rtgi_hip_tracer *h, const rtgi_camera *cam, const float *d_offsets, rtgi_ray *d_rays,
+                                void *stream) {
+	if (!h || !cam) return RTGI_ERR_INVALID;
+	if (h->device < 0) return fail(h, RTGI_ERR_DEVICE, "host-only handle: needs a GPU");
+	if (cam->w <= 0 || cam->h <= 0 || !d_rays || (reinterpret_cast<uintptr_t>(d_rays) & 15u))
+		return fail(h, RTGI_ERR_INVALID, "camera_rays: bad resolution or ray buffer (must be 16-byte aligned)");
+	if ((uint64_t)cam->w * (uint64_t)cam->h > 0x7fffffffull) return fail(h, RTGI_ERR_INVALID, "camera_rays: resolution too large");
+	HIP_TRY(h, hipSetDevice(h->device));
+	rtgi_dev::CamArgs a;
+	const float *d = cam->dir, *u = cam->up;
+	// cross(dir, up) and cross(U, dir) with glm's component formulas (libgi/camera.cpp:13-14)
+	const float U[3] = {d[1] * u[2] - u[1] * d[2], d[2] * u[0] - u[2] * d[0], d[0] * u[1] - u[0] * d[1]};
+	const float V[3] = {U[1] * d[2] - d[1] * U[2], U[2] * d[0] - d[2] * U[0], U[0] * d[1] - d[0] * U[1]};
+	for (int k = 0; k < 3; ++k) a.dir[k] = d[k], a.pos[k] = cam->pos[k], a.U[k] = U[k], a.V[k] = V[k];
+	const float aspect = float(cam->w) / cam->h;  // camera::update_frustum, libgi/camera.h:18-24
+	a.near_h = tanf(float(M_PI) * cam->fovy * 0.5f / 180.0f);
+	a.near_w = aspect * a.near_h;
+	a.w = cam->w, a.h = cam->h;
+	a.offsets = (const float2 *)d_offsets;
+	a.rays = (float4 *)d_rays;
+	const uint32_t n = (uint32_t)cam->w * (uint32_t)cam->h;
+	hipLaunchKernelGGL(rtgi_dev::camera_rays_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+	HIP_TRY(h, hipGetLastError());
+	return RTGI_OK;
+}
+
+int rtgi_hip_shadow_rays_device(rtgi_hip_tracer *h, const rtgi_hit *d_hits, uint32_t n, const float light_pos[3],
+                                rtgi_ray *d_shadow, void *stream) {
+	if (!h || !light_pos) return RTGI_ERR_INVALID;
+	if (h->device < 0) return fail(h, RTGI_ERR_DEVICE, "host-only handle: needs a GPU");
+	if (!h->built) return fail(h, RTGI_ERR_NOT_BUILT, "no acceleration structure: call build first");
+	if (n == 0) return RTGI_OK;
+	if (!d_hits || !d_shadow || ((reinterpret_cast<uintptr_t>(d_hits) | reinterpret_cast<uintptr_t>(d_shadow)) & 15u))
+		return fail(h, RTGI_ERR_INVALID, "shadow_rays: null or misaligned buffer");
+	HIP_TRY(h, hipSetDevice(h->device));
+	rtgi_dev::ShadowArgs a;
+	a.hits = (const float4 *)d_hits;
+	a.corners = h->d_corners;
+	a.out = (float4 *)d_shadow;
+	for (int k = 0; k < 3; ++k) a.light[k] = light_pos[k];
+	a.n = n;
+	hipLaunchKernelGGL(rtgi_dev::shadow_rays_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+	HIP_TRY(h, hipGetLastError());
+	return RTGI_OK;
+}
+
+int rtgi_hip_bounce_rays_device(rtgi_hip_tracer *h, const rtgi_ray *d_rays, const rtgi_hit *d_hits, uint32_t n,
+                                uint32_t seed, uint32_t bounce, rtgi_ray *d_out, uint32_t *d_parent, uint32_t *d_count,
+                                void *stream) {
+	if (!h) return RTGI_ERR_INVALID;
+	if (h->device < 0) return fail(h, RTGI_ERR_DEVICE, "host-only handle: needs a GPU");
+	if (!h->built) return fail(h, RTGI_ERR_NOT_BUILT, "no acceleration structure: call build first");
+	if (!d_count) return fail(h, RTGI_ERR_INVALID, "bounce_rays: d_count is required");
+	HIP_TRY(h, hipSetDevice(h->device));
+	hipStream_t st = (hipStream_t)stream;
+	if (n == 0) {
+		HIP_TRY(h, hipMemsetAsync(d_count, 0, sizeof(uint32_t), st));
+		return RTGI_OK;
+	}
+	if (!d_rays || !d_hits || !d_out ||
+	    ((reinterpret_cast<uintptr_t>(d_rays) | reinterpret_cast<uintptr_t>(d_hits) | reinterpret_cast<uintptr_t>(d_out)) & 15u))
+		return fail(h, RTGI_ERR_INVALID, "bounce_rays: null or misaligned buffer");
+	const uint32_t n_waves = (n + 63) / 64;
+	if (n_waves > h->wave_counts_cap) {
+		if (h->d_wave_counts) (void)hipFree(h->d_wave_counts);
+		h->d_wave_counts = nullptr;
+		h->wave_counts_cap = 0;
+		HIP_TRY(h, hipMalloc((void **)&h->d_wave_counts, (size_t)n_waves * sizeof(uint32_t)));
+		h->wave_counts_cap = n_waves;
+	}
+	rtgi_dev::BounceArgs a;
+	a.rays = (const float4 *)d_rays;
+	a.hits = (const float4 *)d_hits;
+	a.corners = h->d_corners;
+	a.wave_counts = h->d_wave_counts;
+	a.out = (float4 *)d_out;
+	a.parent = d_parent;
+	a.n = n, a.seed = seed, a.bounce = bounce;
+	const uint32_t blocks = (n + 255) / 256;
+	hipLaunchKernelGGL(rtgi_dev::bounce_count_kernel, dim3(blocks), dim3(256), 0, st, a);
+	hipLaunchKernelGGL(rtgi_dev::scan_kernel, dim3(1), dim3(1024), 0, st, h->d_wave_counts, n_waves, d_count);
+	hipLaunchKernelGGL(rtgi_dev::bounce_write_kernel, dim3(blocks), dim3(256), 0, st, a);
+	HIP_TRY(h, hipGetLastError());
+	return RTGI_OK;
 }
 
 const char *rtgi_hip_last_error(const rtgi_hip_tracer *h) { return h ? h->error.c_str() : g_create_error.c_str(); }

@@ -1,0 +1,192 @@
+// wavefront_kernels.h -- the ray populations around the tracer, produced on the GPU so that rays and hits
+// never leave it: camera rays, shadow rays, and diffuse bounce rays with order-preserving compaction.
+// (Device code only; included by rtgi_hip.hip.) File:line citations: "Assignment 3/rtgi-2021-a03-ref/".
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdint>
+
+#include "rtgi_hip.h"
+
+namespace rtgi_dev {
+
+constexpr float RAY_EPS = 1e-4f;  // ray::eps, libgi/rt.h:21
+
+struct CamArgs {
+	float dir[3], pos[3], U[3], V[3];  // U = cross(dir, up), V = cross(U, dir): libgi/camera.cpp:13-14
+	float near_w, near_h;              // libgi/camera.h:22-23
+	int w, h;
+	const float2 *offsets;  // optional sub-pixel jitter per pixel, as the caller's rng would give (camera.cpp:11)
+	float4 *rays;
+};
+
+// cam_ray, libgi/camera.cpp:11-22, for every pixel (batch_cam_ray_setup_cpu, libgi/wavefront-rt.h:90-102)
+__global__ __launch_bounds__(256) void camera_rays_kernel(CamArgs a) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= (uint32_t)a.w * (uint32_t)a.h) return;
+	const int x = (int)(i % (uint32_t)a.w), y = (int)(i / (uint32_t)a.w);
+	float ox = 0.0f, oy = 0.0f;
+	if (a.offsets) {
+		const float2 o = a.offsets[i];
+		ox = o.x, oy = o.y;
+	}
+	float u = ((float)x + 0.5f + ox) / (float)a.w * 2.0f - 1.0f;
+	float v = ((float)y + 0.5f + oy) / (float)a.h * 2.0f - 1.0f;
+	u = a.near_w * u;
+	v = a.near_h * v;
+	// dir + U*u + V*v, then glm::normalize = v * inversesqrt(dot(v, v))
+	const float dx = a.dir[0] + a.U[0] * u + a.V[0] * v;
+	const float dy = a.dir[1] + a.U[1] * u + a.V[1] * v;
+	const float dz = a.dir[2] + a.U[2] * u + a.V[2] * v;
+	const float px = dx * dx, py = dy * dy, pz = dz * dz;
+	const float inv = 1.0f / sqrtf(px + py + pz);
+	a.rays[2 * (size_t)i] = make_float4(a.pos[0], a.pos[1], a.pos[2], dx * inv);
+	a.rays[2 * (size_t)i + 1] = make_float4(dy * inv, dz * inv, RAY_EPS, FLT_MAX);
+}
+
+// Triangle corner positions by the id a hit reports: 3 x float4 per triangle (A, B, C).
+__device__ __forceinline__ void hit_point(const float4 *corners, const float4 hit, float &x, float &y, float &z, float4 &A,
+                                          float4 &B, float4 &C) {
+	const uint32_t id = __float_as_uint(hit.w);
+	A = corners[3 * (size_t)id], B = corners[3 * (size_t)id + 1], C = corners[3 * (size_t)id + 2];
+	const float beta = hit.y, gamma = hit.z;
+	const float alpha = 1.0f - beta - gamma;  // diff_geom::x, libgi/rt.cpp:9
+	x = alpha * A.x + beta * B.x + gamma * C.x;
+	y = alpha * A.y + beta * B.y + gamma * C.y;
+	z = alpha * A.z + beta * B.z + gamma * C.z;
+}
+
+struct ShadowArgs {
+	const float4 *hits;
+	const float4 *corners;
+	float4 *out;
+	float light[3];
+	uint32_t n;
+};
+
+// Shadow rays of gi/primary-hit.cpp:43-50, one slot per input ray: from the hit point towards the light,
+// ending eps before it (length_exclusive). Rays that hit nothing get an empty interval (t_max < t_min), which
+// the tracer answers with "not occluded" after one node.
+__global__ __launch_bounds__(256) void shadow_rays_kernel(ShadowArgs a) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= a.n) return;
+	const float4 hit = a.hits[i];
+	if (hit.x == FLT_MAX) {
+		a.out[2 * (size_t)i] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+		a.out[2 * (size_t)i + 1] = make_float4(0.0f, 0.0f, RAY_EPS, -1.0f);
+		return;
+	}
+	float x, y, z;
+	float4 A, B, C;
+	hit_point(a.corners, hit, x, y, z, A, B, C);
+	const float lx = a.light[0] - x, ly = a.light[1] - y, lz = a.light[2] - z;
+	const float px = lx * lx, py = ly * ly, pz = lz * lz;
+	const float d = sqrtf(px + py + pz);
+	const float inv = 1.0f / d;
+	a.out[2 * (size_t)i] = make_float4(x, y, z, lx * inv);
+	a.out[2 * (size_t)i + 1] = make_float4(ly * inv, lz * inv, RAY_EPS, d - RAY_EPS);
+}
+
+// Counter-based random numbers: a 32-bit finaliser keyed by (ray index, stream, seed); 24 bits per float.
+__device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
+	x ^= x >> 16;
+	x *= 0x7FEB352Du;
+	x ^= x >> 15;
+	x *= 0x846CA68Bu;
+	x ^= x >> 16;
+	return x;
+}
+__device__ __forceinline__ float uniform01(uint32_t index, uint32_t stream, uint32_t seed) {
+	uint32_t key = hash_u32(index * 0x9E3779B1u + stream * 0x85EBCA77u + seed * 0xC2B2AE3Du);
+	key = hash_u32(key ^ 0x27D4EB2Fu);
+	return (float)(key >> 8) * (1.0f / 16777216.0f);
+}
+
+struct BounceArgs {
+	const float4 *rays;
+	const float4 *hits;
+	const float4 *corners;
+	uint32_t *wave_counts;  // pass 1 out, pass 2 in (after the exclusive scan: offsets)
+	float4 *out;
+	uint32_t *parent;  // optional: index of the ray each bounce ray continues
+	uint32_t n, seed, bounce;
+};
+
+// Pass 1: how many rays of each wave hit something (ballot + popcount).
+__global__ __launch_bounds__(256) void bounce_count_kernel(BounceArgs a) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	const bool valid = i < a.n && a.hits[i].x != FLT_MAX;
+	const unsigned long long m = __ballot(valid);
+	if ((threadIdx.x & 63u) == 0) a.wave_counts[i >> 6] = (uint32_t)__popcll(m);
+}
+
+// Exclusive scan of the per-wave counts by one workgroup; total[0] receives the sum.
+__global__ __launch_bounds__(1024) void scan_kernel(uint32_t *counts, uint32_t n, uint32_t *total) {
+	__shared__ uint32_t partial[1024];
+	const uint32_t per = (n + 1023u) / 1024u;
+	const uint32_t begin = threadIdx.x * per, end = min(begin + per, n);
+	uint32_t sum = 0;
+	for (uint32_t i = begin; i < end; ++i) sum += counts[i];
+	partial[threadIdx.x] = sum;
+	__syncthreads();
+	for (uint32_t step = 1; step < 1024u; step <<= 1) {
+		uint32_t v = threadIdx.x >= step ? partial[threadIdx.x - step] : 0u;
+		__syncthreads();
+		partial[threadIdx.x] += v;
+		__syncthreads();
+	}
+	uint32_t run = partial[threadIdx.x] - sum;
+	for (uint32_t i = begin; i < end; ++i) {
+		const uint32_t c = counts[i];
+		counts[i] = run;
+		run += c;
+	}
+	if (threadIdx.x == 1023u) total[0] = partial[1023];
+}
+
+// Pass 2: one diffuse bounce for every ray that hit something, written densely in the order of the input
+// rays: from the hit point into a cosine-weighted random direction about the geometric normal that faces the
+// incoming ray. (The renderer has no path tracer; this is this backend's definition of the bounce population,
+// mirrored on the host by raytracing_amd/wavefront.py.)
+__global__ __launch_bounds__(256) void bounce_write_kernel(BounceArgs a) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	const float4 hit = i < a.n ? a.hits[i] : make_float4(FLT_MAX, 0, 0, 0);
+	const bool valid = i < a.n && hit.x != FLT_MAX;
+	const unsigned long long m = __ballot(valid);
+	if (!valid) return;
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t slot = a.wave_counts[i >> 6] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+	float x, y, z;
+	float4 A, B, C;
+	hit_point(a.corners, hit, x, y, z, A, B, C);
+	const float e1x = B.x - A.x, e1y = B.y - A.y, e1z = B.z - A.z;
+	const float e2x = C.x - A.x, e2y = C.y - A.y, e2z = C.z - A.z;
+	float nx = e1y * e2z - e1z * e2y, ny = e1z * e2x - e1x * e2z, nz = e1x * e2y - e1y * e2x;
+	const float nl = fmaxf(sqrtf(nx * nx + ny * ny + nz * nz), 1e-30f);
+	nx /= nl, ny /= nl, nz /= nl;
+	const float4 r0 = a.rays[2 * (size_t)i], r1 = a.rays[2 * (size_t)i + 1];
+	if (nx * r0.w + ny * r1.x + nz * r1.y > 0.0f) nx = -nx, ny = -ny, nz = -nz;
+	const float u1 = uniform01(i, 2u * a.bounce, a.seed), u2 = uniform01(i, 2u * a.bounce + 1u, a.seed);
+	const float r = sqrtf(u1), phi = 6.2831853071795864769f * u2;
+	float sn, cs;
+	sincosf(phi, &sn, &cs);
+	const float lx = r * cs, ly = r * sn, lz = sqrtf(fmaxf(0.0f, 1.0f - u1));
+	// orthonormal basis around n (Duff et al., branchless)
+	const float sign = nz >= 0.0f ? 1.0f : -1.0f;
+	const float aa = -1.0f / (sign + nz);
+	const float bb = nx * ny * aa;
+	const float t1x = 1.0f + sign * nx * nx * aa, t1y = sign * bb, t1z = -sign * nx;
+	const float t2x = bb, t2y = sign + ny * ny * aa, t2z = -ny;
+	float dx = t1x * lx + t2x * ly + nx * lz;
+	float dy = t1y * lx + t2y * ly + ny * lz;
+	float dz = t1z * lx + t2z * ly + nz * lz;
+	const float dl = sqrtf(dx * dx + dy * dy + dz * dz);
+	dx /= dl, dy /= dl, dz /= dl;
+	a.out[2 * (size_t)slot] = make_float4(x, y, z, dx);
+	a.out[2 * (size_t)slot + 1] = make_float4(dy, dz, RAY_EPS, FLT_MAX);
+	if (a.parent) a.parent[slot] = i;
+}
+
+}  // namespace rtgi_dev

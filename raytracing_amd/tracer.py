@@ -25,7 +25,8 @@ EXPORTS = [
     "rtgi_hip_device_count", "rtgi_hip_create", "rtgi_hip_destroy", "rtgi_hip_interprete", "rtgi_hip_build",
     "rtgi_hip_upload_bvh", "rtgi_hip_num_nodes", "rtgi_hip_num_index", "rtgi_hip_root", "rtgi_hip_depth",
     "rtgi_hip_get_nodes", "rtgi_hip_get_triangle_order", "rtgi_hip_closest_hit", "rtgi_hip_any_hit",
-    "rtgi_hip_closest_hit_device", "rtgi_hip_any_hit_device", "rtgi_hip_last_error",
+    "rtgi_hip_closest_hit_device", "rtgi_hip_any_hit_device", "rtgi_hip_camera_rays_device",
+    "rtgi_hip_shadow_rays_device", "rtgi_hip_bounce_rays_device", "rtgi_hip_last_error",
 ]
 
 
@@ -66,6 +67,9 @@ def lib():
         L.rtgi_hip_any_hit.argtypes = [vp, vp, u32, vp]
         L.rtgi_hip_closest_hit_device.argtypes = [vp, vp, u32, vp, vp, vp]
         L.rtgi_hip_any_hit_device.argtypes = [vp, vp, u32, vp, vp, vp]
+        L.rtgi_hip_camera_rays_device.argtypes = [vp, vp, vp, vp, vp]
+        L.rtgi_hip_shadow_rays_device.argtypes = [vp, vp, u32, vp, vp, vp]
+        L.rtgi_hip_bounce_rays_device.argtypes = [vp, vp, vp, u32, u32, u32, vp, vp, vp, vp]
         L.rtgi_hip_last_error.argtypes = [vp]
         L.rtgi_hip_last_error.restype = cp
         _lib = L
@@ -181,6 +185,45 @@ class HipBvhTracer:
         self._check(lib().rtgi_hip_any_hit_device(
             self._h, d_rays.data_ptr(), n, d_occluded.data_ptr(), d_counts.data_ptr() if d_counts is not None else None,
             self._stream(stream)))
+
+    # -- ray populations on the device (wavefront stages around the tracer) ---------------------------------
+    def camera_rays_device(self, cam_dir, cam_pos, cam_up, fovy, w, h, d_offsets=None, stream=None):
+        """cam_ray for every pixel (libgi/camera.cpp:11-22) -> float32 (w*h, 8) cuda tensor."""
+        import torch
+
+        class Cam(C.Structure):
+            _fields_ = [("dir", C.c_float * 3), ("pos", C.c_float * 3), ("up", C.c_float * 3), ("fovy", C.c_float),
+                        ("w", C.c_int32), ("h", C.c_int32)]
+        cam = Cam((C.c_float * 3)(*cam_dir), (C.c_float * 3)(*cam_pos), (C.c_float * 3)(*cam_up), fovy, w, h)
+        d_rays = torch.empty((w * h, 8), dtype=torch.float32, device="cuda:%d" % self.device)
+        if d_offsets is not None and (d_offsets.dtype != torch.float32 or d_offsets.numel() != 2 * w * h
+                                      or not d_offsets.is_contiguous() or d_offsets.device.index != self.device):
+            raise ValueError("d_offsets must be a contiguous float32 tensor of w*h*2 values on the tracer's GPU")
+        self._check(lib().rtgi_hip_camera_rays_device(self._h, C.byref(cam), d_offsets.data_ptr() if d_offsets is not None else None,
+                                                      d_rays.data_ptr(), self._stream(stream)))
+        return d_rays
+
+    def shadow_rays_device(self, d_hits, light_pos, stream=None):
+        """Shadow rays towards a point light, one slot per hit record (gi/primary-hit.cpp:43-50)."""
+        import torch
+        n = d_hits.shape[0]
+        d_out = torch.empty((n, 8), dtype=torch.float32, device=d_hits.device)
+        light = (C.c_float * 3)(*light_pos)
+        self._check(lib().rtgi_hip_shadow_rays_device(self._h, d_hits.data_ptr(), n, light, d_out.data_ptr(), self._stream(stream)))
+        return d_out
+
+    def bounce_rays_device(self, d_rays, d_hits, seed=0, bounce=1, stream=None, want_parent=False):
+        """One diffuse bounce off every hit, compacted in parent order. Returns (rays (m, 8), parent (m,) or None)."""
+        import torch
+        n = d_rays.shape[0]
+        d_out = torch.empty((max(n, 1), 8), dtype=torch.float32, device=d_rays.device)
+        d_parent = torch.empty(max(n, 1), dtype=torch.int32, device=d_rays.device) if want_parent else None
+        d_count = torch.zeros(1, dtype=torch.int32, device=d_rays.device)
+        self._check(lib().rtgi_hip_bounce_rays_device(
+            self._h, d_rays.data_ptr(), d_hits.data_ptr(), n, seed, bounce, d_out.data_ptr(),
+            d_parent.data_ptr() if want_parent else None, d_count.data_ptr(), self._stream(stream)))
+        m = int(d_count.item())
+        return d_out[:m], (d_parent[:m] if want_parent else None)
 
     def _check_device_args(self, d_rays, d_out, out_width, d_counts):
         import torch

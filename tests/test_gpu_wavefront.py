@@ -1,0 +1,129 @@
+"""The ray-producing stages around the tracer (camera rays, shadow rays, bounce rays with compaction) on the
+GPU, against the oracle's cam_ray and the host definitions in raytracing_amd/wavefront.py."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from raytracing_amd import scenes, tracer, wavefront
+from tests.util import FLT_MAX, assert_hits_equal, obj_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _hits_of(d_hits):
+    return d_hits.cpu().numpy().view(tracer.HIT_DTYPE).reshape(-1)
+
+
+def test_camera_rays_match_oracle_and_the_assignment2_dump(golden_dir):
+    import torch
+    t = tracer.HipBvhTracer(layout="indexed")
+    cam = ([1, 0, 0], [-13, -12, 0], [0, 1, 0], 65.0, 1280, 720)
+    got = t.camera_rays_device(*cam).cpu().numpy()
+    want = orc.cam_rays(*cam)
+    assert got.tobytes() == want.tobytes()                      # bit-identical to the CPU restatement
+    with gzip.open(os.path.join(golden_dir, "a2_camrays_test.obj.gz"), "rt") as f:
+        vs = [l for l in f.read().split("\n") if l.startswith("v ")]
+    img = got.reshape(720, 1280, 8)[::10, ::10].reshape(-1, 8)  # test_camrays dumps every 10th pixel
+    assert len(img) == 9216
+    for i in range(0, 9216, 7):
+        assert "v %g %g %g" % tuple(float(x) for x in img[i, 3:6]) == vs[2 * i + 1]
+    # with sub-pixel offsets
+    rs = np.random.RandomState(1)
+    off = (rs.rand(48, 64, 2).astype(np.float32) - 0.5)
+    cam2 = ([0, 0, -1], [0, 0, 0], [0, 1, 0], 65.0, 64, 48)
+    got = t.camera_rays_device(*cam2, d_offsets=torch.from_numpy(off).cuda()).cpu().numpy()
+    assert got.tobytes() == orc.cam_rays(*cam2, offsets=off).tobytes()
+
+
+def test_primary_and_shadow_rays_brdf_test_scene():
+    # scripts/a3-brdf-test: camera, point light at (2, 1.5, 0); primary closest_hit then one any_hit per pixel
+    import torch
+    pos, tri, _ = obj_scene("brdf-test-noal.obj")
+    t = tracer.HipBvhTracer(layout="indexed")
+    t.build(pos, tri)
+    o = orc.Bbvh(pos, tri, layout="indexed")
+    cam_dir = np.array([0.85235, -0.52249, -0.022323], np.float32)
+    cam = (cam_dir, [-2.4008, 1.7537, -0.050779], [0.52233, 0.85264, -0.013184], 65.0, 320, 180)
+    d_rays = t.camera_rays_device(*cam)
+    d_hits = torch.empty((d_rays.shape[0], 4), dtype=torch.float32, device="cuda")
+    t.closest_hit_device(d_rays, d_hits)
+    rays = d_rays.cpu().numpy()
+    hits = _hits_of(d_hits)
+    assert_hits_equal(hits, o.closest_hit(rays), "primary")
+    valid = hits["t"] != FLT_MAX
+    assert 0.2 < valid.mean() < 1.0
+    d_shadow = t.shadow_rays_device(d_hits, [2, 1.5, 0])
+    shadow = d_shadow.cpu().numpy()
+    want = wavefront.shadow_rays(wavefront.hit_points(pos, tri, hits[valid]), [2, 1.5, 0])
+    np.testing.assert_allclose(shadow[valid, 0:3], want[:, 0:3], rtol=0, atol=0)     # hit points: same fp32 ops
+    np.testing.assert_allclose(shadow[valid, 3:8], want[:, 3:8], rtol=2e-6, atol=1e-6)
+    assert (shadow[~valid, 7] < shadow[~valid, 6]).all()                             # empty interval for misses
+    d_occ = torch.empty(len(shadow), dtype=torch.uint8, device="cuda")
+    t.any_hit_device(d_shadow, d_occ)
+    occ = d_occ.cpu().numpy()
+    assert (occ == o.any_hit(shadow)).all()
+    assert (occ[~valid] == 0).all()          # this scene is a set of floor planes: nothing shadows anything
+
+
+def test_shadow_rays_find_occluders_in_a_box_scene():
+    import torch
+    pos, tri, _ = scenes.cornell(2)
+    t = tracer.HipBvhTracer(layout="flat")
+    t.build(pos, tri)
+    o = orc.Bbvh(pos, tri, layout="flat")
+    d_rays = t.camera_rays_device([0, 0, -1], [0, 0, 3.2], [0, 1, 0], 40.0, 256, 256)
+    d_hits = torch.empty((d_rays.shape[0], 4), dtype=torch.float32, device="cuda")
+    t.closest_hit_device(d_rays, d_hits)
+    hits = _hits_of(d_hits)
+    valid = hits["t"] != FLT_MAX
+    assert valid.mean() > 0.9
+    d_shadow = t.shadow_rays_device(d_hits, [0.0, 0.9, 0.3])
+    d_occ = torch.empty(d_shadow.shape[0], dtype=torch.uint8, device="cuda")
+    t.any_hit_device(d_shadow, d_occ)
+    occ = d_occ.cpu().numpy()
+    assert (occ == o.any_hit(d_shadow.cpu().numpy())).all()
+    assert 0.02 < occ[valid].mean() < 0.6                      # the two boxes cast shadows
+
+
+def test_bounce_rays_and_compaction():
+    import torch
+    pos, tri, _ = scenes.soup(30000, seed=2, size=0.3)
+    t = tracer.HipBvhTracer(layout="flat")
+    t.build(pos, tri)
+    tri_flat = tri[t.triangle_order()]
+    rays = scenes.random_rays(50001, seed=3)
+    d_rays = torch.from_numpy(rays).cuda()
+    d_hits = torch.empty((len(rays), 4), dtype=torch.float32, device="cuda")
+    t.closest_hit_device(d_rays, d_hits)
+    hits = _hits_of(d_hits)
+    d_bounce, d_parent = t.bounce_rays_device(d_rays, d_hits, seed=5, bounce=1, want_parent=True)
+    got, parent = d_bounce.cpu().numpy(), d_parent.cpu().numpy()
+    want, want_parent = wavefront.bounce_rays(pos, tri_flat, rays, hits, seed=5, bounce=1)
+    assert len(got) == len(want) == int((hits["t"] != FLT_MAX).sum()) > 1000
+    assert (parent == want_parent).all()                          # dense, in parent order
+    assert got[:, 0:3].tobytes() == want[:, 0:3].tobytes()        # origins: same fp32 operations
+    np.testing.assert_allclose(got[:, 3:6], want[:, 3:6], rtol=0, atol=2e-5)
+    assert (got[:, 6] == np.float32(1e-4)).all() and (got[:, 7] == FLT_MAX).all()
+    np.testing.assert_allclose(np.linalg.norm(got[:, 3:6].astype(np.float64), axis=1), 1.0, atol=1e-6)
+    # the bounce directions leave the surface on the side the ray came from
+    v = pos[tri_flat[hits["ref"][want_parent]]].astype(np.float64)
+    n = np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0])
+    side_in = np.sign((n * rays[want_parent, 3:6]).sum(1))
+    side_out = np.sign((n * got[:, 3:6]).sum(1))
+    assert (side_in * side_out <= 0).mean() > 0.999
+    # tracing the bounce batch agrees with the oracle on the same rays
+    o = orc.Bbvh(pos, tri, layout="flat")
+    d_hits2 = torch.empty((len(got), 4), dtype=torch.float32, device="cuda")
+    t.closest_hit_device(d_bounce.contiguous(), d_hits2)
+    assert_hits_equal(_hits_of(d_hits2), o.closest_hit(got), "bounce batch")
+    # nothing hit -> empty batch
+    far = rays.copy()
+    far[:, 0:3] += 1000.0
+    far[:, 3:6] = [1, 0, 0]
+    d_far = torch.from_numpy(far).cuda()
+    t.closest_hit_device(d_far, d_hits)
+    empty, _ = t.bounce_rays_device(d_far, d_hits)
+    assert empty.shape[0] == 0
