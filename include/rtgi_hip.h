@@ -72,7 +72,9 @@ rtgi_hip_tracer *rtgi_hip_create(int device, int layout, int esc);
 void rtgi_hip_destroy(rtgi_hip_tracer *h);
 
 /* ray_tracer::interprete(command, in), bvh2.cpp:503-555: `args` is the rest of the command line.
- * Handles "bvh om | sm | sah N | triangles single | triangles multiple N | statistics | export D file".
+ * Handles "bvh om | sm | sah N | triangles single | triangles multiple N | statistics | export D file" and
+ * the backend's own "hip reorder on | off" (sort large ray batches spatially before tracing; default on;
+ * results do not depend on it).
  * Returns 1 if the command was consumed, 0 if it is not for this tracer, RTGI_ERR_SYNTAX if it was
  * recognised but malformed (the reference prints an error and still reports "consumed"). */
 int rtgi_hip_interprete(rtgi_hip_tracer *h, const char *command, const char *args);
@@ -154,6 +156,13 @@ int rtgi_hip_shadow_rays_device(rtgi_hip_tracer *h, const rtgi_hit *d_hits, uint
 int rtgi_hip_bounce_rays_device(rtgi_hip_tracer *h, const rtgi_ray *d_rays, const rtgi_hit *d_hits, uint32_t n,
                                 uint32_t seed, uint32_t bounce, rtgi_ray *d_out, uint32_t *d_parent, uint32_t *d_count,
                                 void *stream);
+
+/* Timing of the traversal kernel alone (what the reference's time_this_block(closest_hit), bvh2.cpp:417,
+ * measures per call, here per launch): after profile_begin every closest_hit / any_hit launch is bracketed by
+ * HIP events on its stream; profile_end waits for them and returns the summed kernel time and the number of
+ * launches (at most 4096 are kept). Sorting and copies are not included. */
+int rtgi_hip_profile_begin(rtgi_hip_tracer *h);
+int rtgi_hip_profile_end(rtgi_hip_tracer *h, double *kernel_ms_total, uint32_t *launches);
 
 /* Text of the last error on this handle (h may be NULL: last error of a failed create). */
 const char *rtgi_hip_last_error(const rtgi_hip_tracer *h);

@@ -2,6 +2,7 @@
 //
 // The traversal kernel itself is in trace_kernel.h; this file holds the handle, the uploads and the launches.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <cfloat>
 #include <cmath>
@@ -44,6 +45,19 @@ struct rtgi_hip_tracer {
 	float4 *d_corners = nullptr;  // triangle corners by reported id
 	uint32_t *d_wave_counts = nullptr;
 	size_t wave_counts_cap = 0;
+
+	// per-launch kernel timing (profile_begin / profile_end)
+	bool profiling = false;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+	size_t events_used = 0;
+
+	// spatial reordering of ray batches ("hip reorder on|off")
+	bool reorder = true;
+	uint32_t reorder_min = 1u << 16;  // smaller batches are traced as they come
+	float scene_lo[3] = {0, 0, 0}, scene_inv_extent[3] = {1, 1, 1};
+	uint32_t *d_sort = nullptr;  // keys in, keys out, index in, index out
+	void *d_sort_temp = nullptr;
+	size_t sort_cap = 0, sort_temp_bytes = 0;
 	uint32_t node_bytes = 0, tri_bytes = 0;
 	int refill_min = 16, leaf_min = 8;
 	uint32_t n_segments = 8;
@@ -117,8 +131,52 @@ int upload(rtgi_hip_tracer *h, const rtgi::SceneView &scene) {
 	if (h->spill_levels)
 		HIP_TRY(h, hipMalloc((void **)&h->d_spill, (size_t)h->spill_levels * h->grid_blocks * BLOCK * sizeof(int32_t)));
 	if (!h->d_counter) HIP_TRY(h, hipMalloc((void **)&h->d_counter, 8 * rtgi_dev::COUNTER_STRIDE * sizeof(uint32_t)));
+	// bounds of the whole scene (union of the root's child boxes, or of the single leaf's triangles)
+	float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+	for (uint32_t v = 0; v < scene.n_vertices; ++v)
+		for (int k = 0; k < 3; ++k) {
+			lo[k] = std::min(lo[k], scene.pos(v)[k]);
+			hi[k] = std::max(hi[k], scene.pos(v)[k]);
+		}
+	for (int k = 0; k < 3; ++k) {
+		h->scene_lo[k] = lo[k];
+		h->scene_inv_extent[k] = hi[k] > lo[k] ? 1.0f / (hi[k] - lo[k]) : 0.0f;
+	}
+	if (const char *e = getenv("RTGI_HIP_REORDER")) h->reorder = atoi(e) != 0;
 	h->root_ref = flat.root_ref;
 	h->built = true;
+	return RTGI_OK;
+}
+
+// Sorts the batch by (direction octant, Morton code of the origin); leaves the permutation in the fourth
+// quarter of d_sort. Buffers grow on demand and are kept.
+int sort_rays(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint32_t n, hipStream_t stream) {
+	if (n > h->sort_cap) {
+		if (h->d_sort) (void)hipFree(h->d_sort);
+		if (h->d_sort_temp) (void)hipFree(h->d_sort_temp);
+		h->d_sort = nullptr;
+		h->d_sort_temp = nullptr;
+		h->sort_cap = 0;
+		const size_t cap = (size_t)n + n / 8 + 1024;
+		HIP_TRY(h, hipMalloc((void **)&h->d_sort, 4 * cap * sizeof(uint32_t)));
+		size_t temp = 0;
+		HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(nullptr, temp, h->d_sort, h->d_sort + cap, h->d_sort + 2 * cap,
+		                                            h->d_sort + 3 * cap, (int)cap, 0, 30, stream));
+		HIP_TRY(h, hipMalloc(&h->d_sort_temp, temp));
+		h->sort_temp_bytes = temp;
+		h->sort_cap = cap;
+	}
+	const size_t cap = h->sort_cap;
+	rtgi_dev::KeyArgs k;
+	k.rays = (const float4 *)d_rays;
+	k.keys = h->d_sort;
+	k.index = h->d_sort + 2 * cap;
+	for (int c = 0; c < 3; ++c) k.lo[c] = h->scene_lo[c], k.inv_extent[c] = h->scene_inv_extent[c];
+	k.n = n;
+	hipLaunchKernelGGL(rtgi_dev::ray_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, k);
+	size_t temp = h->sort_temp_bytes;
+	HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(h->d_sort_temp, temp, h->d_sort, h->d_sort + cap, h->d_sort + 2 * cap,
+	                                            h->d_sort + 3 * cap, (int)n, 0, 30, stream));
 	return RTGI_OK;
 }
 
@@ -151,7 +209,26 @@ int launch(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint32_t n, void *d_out, 
 	uint32_t blocks = (n + BLOCK - 1) / BLOCK;
 	if (blocks > h->grid_blocks) blocks = h->grid_blocks;
 	a.spill_stride = blocks * BLOCK;
+	a.order = nullptr;
+	if (h->reorder && n >= h->reorder_min) {
+		int rc = sort_rays(h, d_rays, n, stream);
+		if (rc) return rc;
+		a.order = h->d_sort + 3 * h->sort_cap;
+	}
 	HIP_TRY(h, hipMemsetAsync(h->d_counter, 0, 8 * rtgi_dev::COUNTER_STRIDE * sizeof(uint32_t), stream));
+	hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+	if (h->profiling && h->events_used < 4096) {
+		if (h->events_used == h->events.size()) {
+			hipEvent_t e0, e1;
+			HIP_TRY(h, hipEventCreate(&e0));
+			HIP_TRY(h, hipEventCreate(&e1));
+			h->events.push_back({e0, e1});
+		}
+		ev_start = h->events[h->events_used].first;
+		ev_stop = h->events[h->events_used].second;
+		++h->events_used;
+		HIP_TRY(h, hipEventRecord(ev_start, stream));
+	}
 	const bool deep = h->spill_levels > 0;  // the tree is deeper than the LDS part of the stack
 	if (d_counts && deep)
 		hipLaunchKernelGGL((trace_kernel<ANY, true, true>), dim3(blocks), dim3(BLOCK), 0, stream, a);
@@ -161,6 +238,7 @@ int launch(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint32_t n, void *d_out, 
 		hipLaunchKernelGGL((trace_kernel<ANY, false, true>), dim3(blocks), dim3(BLOCK), 0, stream, a);
 	else
 		hipLaunchKernelGGL((trace_kernel<ANY, false, false>), dim3(blocks), dim3(BLOCK), 0, stream, a);
+	if (ev_stop) HIP_TRY(h, hipEventRecord(ev_stop, stream));
 	HIP_TRY(h, hipGetLastError());
 	return RTGI_OK;
 }
@@ -244,15 +322,31 @@ void rtgi_hip_destroy(rtgi_hip_tracer *h) {
 	if (h->d_stage_rays) (void)hipFree(h->d_stage_rays);
 	if (h->d_stage_out) (void)hipFree(h->d_stage_out);
 	if (h->d_wave_counts) (void)hipFree(h->d_wave_counts);
+	if (h->d_sort) (void)hipFree(h->d_sort);
+	if (h->d_sort_temp) (void)hipFree(h->d_sort_temp);
+	for (auto &e : h->events) {
+		(void)hipEventDestroy(e.first);
+		(void)hipEventDestroy(e.second);
+	}
 	delete h;
 }
 
 int rtgi_hip_interprete(rtgi_hip_tracer *h, const char *command, const char *args) {
 	if (!h || !command) return RTGI_ERR_INVALID;
-	if (std::string(command) != "bvh") return 0;
 	std::istringstream in(args ? args : "");
 	std::string value;
 	in >> value;
+	if (std::string(command) == "hip") {  // backend-specific options, through the same hook as "bvh ..."
+		if (value == "reorder") {
+			std::string onoff;
+			in >> onoff;
+			if (onoff != "on" && onoff != "off") return fail(h, RTGI_ERR_SYNTAX, "Syntax error, \"hip reorder\" requires on or off");
+			h->reorder = onoff == "on";
+			return 1;
+		}
+		return fail(h, RTGI_ERR_SYNTAX, "Unknown hip subcommand " + value);
+	}
+	if (std::string(command) != "bvh") return 0;
 	auto complete = [&]() { return !(in.bad() || in.fail()) && (in >> std::ws).eof(); };
 	if (value == "om") {
 		h->cfg.split = RTGI_SPLIT_OM;
@@ -475,6 +569,32 @@ int rtgi_hip_bounce_rays_device(rtgi_hip_tracer *h, const rtgi_ray *d_rays, cons
 	hipLaunchKernelGGL(rtgi_dev::scan_kernel, dim3(1), dim3(1024), 0, st, h->d_wave_counts, n_waves, d_count);
 	hipLaunchKernelGGL(rtgi_dev::bounce_write_kernel, dim3(blocks), dim3(256), 0, st, a);
 	HIP_TRY(h, hipGetLastError());
+	return RTGI_OK;
+}
+
+int rtgi_hip_profile_begin(rtgi_hip_tracer *h) {
+	if (!h) return RTGI_ERR_INVALID;
+	if (h->device < 0) return fail(h, RTGI_ERR_DEVICE, "host-only handle: needs a GPU");
+	h->profiling = true;
+	h->events_used = 0;
+	return RTGI_OK;
+}
+
+int rtgi_hip_profile_end(rtgi_hip_tracer *h, double *kernel_ms_total, uint32_t *launches) {
+	if (!h || !kernel_ms_total || !launches) return RTGI_ERR_INVALID;
+	if (h->device < 0) return fail(h, RTGI_ERR_DEVICE, "host-only handle: needs a GPU");
+	HIP_TRY(h, hipSetDevice(h->device));
+	double total = 0.0;
+	for (size_t i = 0; i < h->events_used; ++i) {
+		HIP_TRY(h, hipEventSynchronize(h->events[i].second));
+		float ms = 0.0f;
+		HIP_TRY(h, hipEventElapsedTime(&ms, h->events[i].first, h->events[i].second));
+		total += ms;
+	}
+	*kernel_ms_total = total;
+	*launches = (uint32_t)h->events_used;
+	h->profiling = false;
+	h->events_used = 0;
 	return RTGI_OK;
 }
 

@@ -40,6 +40,7 @@ struct TraceArgs {
 	const void *nodes;      // 64 B per inner node, see pack_node() in bvh_host.cpp
 	const void *tris;       // 48 B per leaf-order slot
 	const float4 *rays;     // 32 B per ray: o.xyz d.x | d.yz t_min t_max
+	const uint32_t *order;  // optional: the i-th ray to trace is rays[order[i]] (spatially sorted batches)
 	float4 *hits;           // closest_hit output
 	uint8_t *occluded;      // any_hit output
 	uint32_t *counts;       // optional: 2 per ray
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 			}
 			const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
 			if (cur == IDLE && rank < avail) {
-				const uint32_t mine = first + rank;
+				const uint32_t mine = a.order ? a.order[first + rank] : first + rank;
 				const float4 q0 = a.rays[2 * (size_t)mine], q1 = a.rays[2 * (size_t)mine + 1];
 				ox = q0.x, oy = q0.y, oz = q0.z;
 				dx = q0.w, dy = q1.x, dz = q1.y;
@@ -308,6 +309,38 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 				advance();
 		}
 	}
+}
+
+// Sort key of a ray: direction octant (3 bits) above a 27-bit Morton code of the origin inside the scene's
+// bounds. Rays that start close together and head the same way end up in the same waves and walk the same
+// nodes, which the caches reward; the order of tracing does not change any ray's result.
+struct KeyArgs {
+	const float4 *rays;
+	uint32_t *keys;
+	uint32_t *index;
+	float lo[3], inv_extent[3];
+	uint32_t n;
+};
+__device__ __forceinline__ uint32_t spread3(uint32_t v) {  // 9 bits -> every third bit
+	v = (v | (v << 16)) & 0x030000FFu;
+	v = (v | (v << 8)) & 0x0300F00Fu;
+	v = (v | (v << 4)) & 0x030C30C3u;
+	v = (v | (v << 2)) & 0x09249249u;
+	return v;
+}
+__global__ __launch_bounds__(256) void ray_keys_kernel(KeyArgs a) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= a.n) return;
+	const float4 q0 = a.rays[2 * (size_t)i], q1 = a.rays[2 * (size_t)i + 1];
+	auto cell = [](float x, float lo, float inv) {
+		const float f = (x - lo) * inv * 511.0f;
+		return (uint32_t)__builtin_fminf(__builtin_fmaxf(f == f ? f : 0.0f, 0.0f), 511.0f);
+	};
+	const uint32_t morton = spread3(cell(q0.x, a.lo[0], a.inv_extent[0])) | (spread3(cell(q0.y, a.lo[1], a.inv_extent[1])) << 1) |
+	                        (spread3(cell(q0.z, a.lo[2], a.inv_extent[2])) << 2);
+	const uint32_t octant = (q0.w < 0.0f ? 1u : 0u) | (q1.x < 0.0f ? 2u : 0u) | (q1.y < 0.0f ? 4u : 0u);
+	a.keys[i] = (octant << 27) | morton;
+	a.index[i] = i;
 }
 
 }  // namespace rtgi_dev

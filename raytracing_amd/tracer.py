@@ -26,7 +26,8 @@ EXPORTS = [
     "rtgi_hip_upload_bvh", "rtgi_hip_num_nodes", "rtgi_hip_num_index", "rtgi_hip_root", "rtgi_hip_depth",
     "rtgi_hip_get_nodes", "rtgi_hip_get_triangle_order", "rtgi_hip_closest_hit", "rtgi_hip_any_hit",
     "rtgi_hip_closest_hit_device", "rtgi_hip_any_hit_device", "rtgi_hip_camera_rays_device",
-    "rtgi_hip_shadow_rays_device", "rtgi_hip_bounce_rays_device", "rtgi_hip_last_error",
+    "rtgi_hip_shadow_rays_device", "rtgi_hip_bounce_rays_device", "rtgi_hip_profile_begin", "rtgi_hip_profile_end",
+    "rtgi_hip_last_error",
 ]
 
 
@@ -70,6 +71,8 @@ def lib():
         L.rtgi_hip_camera_rays_device.argtypes = [vp, vp, vp, vp, vp]
         L.rtgi_hip_shadow_rays_device.argtypes = [vp, vp, u32, vp, vp, vp]
         L.rtgi_hip_bounce_rays_device.argtypes = [vp, vp, vp, u32, u32, u32, vp, vp, vp, vp]
+        L.rtgi_hip_profile_begin.argtypes = [vp]
+        L.rtgi_hip_profile_end.argtypes = [vp, vp, vp]
         L.rtgi_hip_last_error.argtypes = [vp]
         L.rtgi_hip_last_error.restype = cp
         _lib = L
@@ -224,6 +227,15 @@ class HipBvhTracer:
             d_parent.data_ptr() if want_parent else None, d_count.data_ptr(), self._stream(stream)))
         m = int(d_count.item())
         return d_out[:m], (d_parent[:m] if want_parent else None)
+
+    def profile_begin(self):
+        self._check(lib().rtgi_hip_profile_begin(self._h))
+
+    def profile_end(self):
+        """(summed traversal-kernel time in ms, number of launches) since profile_begin."""
+        ms, n = C.c_double(0.0), C.c_uint32(0)
+        self._check(lib().rtgi_hip_profile_end(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def _check_device_args(self, d_rays, d_out, out_width, d_counts):
         import torch
