@@ -54,7 +54,12 @@ struct rtgi_hip_tracer {
 	// spatial reordering of ray batches ("hip reorder on|off")
 	bool reorder = true;
 	uint32_t reorder_min = 1u << 16;  // smaller batches are traced as they come
-	float scene_lo[3] = {0, 0, 0}, scene_inv_extent[3] = {1, 1, 1};
+	// All 32 key bits are sorted: with a sub-range of bits (begin_bit = 8) rocPRIM's radix sort of ROCm 7.2 returns
+	// wrong permutations for batches of up to a few 100 k items (scripts/ubench/sort_check.hip).
+	int sort_begin_bit = 0;
+	bool octant_segments = true;
+	uint32_t class_bits = 3;
+	float scene_lo[3] = {0, 0, 0}, scene_hi[3] = {1, 1, 1}, scene_inv_extent[3] = {1, 1, 1};
 	uint32_t *d_sort = nullptr;  // keys in, keys out, index in, index out
 	void *d_sort_temp = nullptr;
 	size_t sort_cap = 0, sort_temp_bytes = 0;
@@ -106,7 +111,7 @@ int upload(rtgi_hip_tracer *h, const rtgi::SceneView &scene) {
 	HIP_TRY(h, hipGetDeviceProperties(&prop, h->device));
 	// persistent grid: workgroups of 4 waves, one wave per SIMD each; default 4 per CU = 4 waves per SIMD (the kernel is issue-bound: more resident waves gain nothing
 	// and leave each lane fewer rays to amortise its drain phase over)
-	uint32_t per_cu = 4;
+	uint32_t per_cu = 3;
 	if (const char *e = getenv("RTGI_HIP_BLOCKS_PER_CU")) per_cu = (uint32_t)std::max(1, std::min(16, atoi(e)));
 	h->grid_blocks = (uint32_t)prop.multiProcessorCount * per_cu;
 	// a near-first depth-first walk never has more pending entries than one per level
@@ -130,7 +135,7 @@ int upload(rtgi_hip_tracer *h, const rtgi::SceneView &scene) {
 	HIP_TRY(h, hipMemcpy(h->d_corners, flat.corners.data(), flat.corners.size() * sizeof(float), hipMemcpyHostToDevice));
 	if (h->spill_levels)
 		HIP_TRY(h, hipMalloc((void **)&h->d_spill, (size_t)h->spill_levels * h->grid_blocks * BLOCK * sizeof(int32_t)));
-	if (!h->d_counter) HIP_TRY(h, hipMalloc((void **)&h->d_counter, 8 * rtgi_dev::COUNTER_STRIDE * sizeof(uint32_t)));
+	if (!h->d_counter) HIP_TRY(h, hipMalloc((void **)&h->d_counter, (8 * rtgi_dev::COUNTER_STRIDE + 16) * sizeof(uint32_t)));
 	// bounds of the whole scene (union of the root's child boxes, or of the single leaf's triangles)
 	float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
 	for (uint32_t v = 0; v < scene.n_vertices; ++v)
@@ -140,12 +145,29 @@ int upload(rtgi_hip_tracer *h, const rtgi::SceneView &scene) {
 		}
 	for (int k = 0; k < 3; ++k) {
 		h->scene_lo[k] = lo[k];
+		h->scene_hi[k] = hi[k];
 		h->scene_inv_extent[k] = hi[k] > lo[k] ? 1.0f / (hi[k] - lo[k]) : 0.0f;
 	}
 	if (const char *e = getenv("RTGI_HIP_REORDER")) h->reorder = atoi(e) != 0;
+	if (const char *e = getenv("RTGI_HIP_OCTANT_SEGMENTS")) h->octant_segments = atoi(e) != 0;
+	if (const char *e = getenv("RTGI_HIP_CLASS_BITS")) h->class_bits = (uint32_t)std::max(0, std::min(4, atoi(e)));
 	h->root_ref = flat.root_ref;
 	h->built = true;
 	return RTGI_OK;
+}
+
+// RTGI_HIP_DEBUG_SYNC=1: wait for the stream after every stage and name the stage on stderr, so that a
+// failing launch can be told from its neighbours.
+hipError_t debug_sync(rtgi_hip_tracer *h, const char *stage, hipStream_t stream) {
+	static const bool on = getenv("RTGI_HIP_DEBUG_SYNC") != nullptr;
+	hipError_t e = hipGetLastError();
+	if (e == hipSuccess && on) {
+		e = hipStreamSynchronize(stream);
+		fprintf(stderr, "[rtgi_hip] %s: %s\n", stage, hipGetErrorString(e));
+		fflush(stderr);
+	}
+	(void)h;
+	return e;
 }
 
 // Sorts the batch by (direction octant, Morton code of the origin); leaves the permutation in the fourth
@@ -153,30 +175,44 @@ int upload(rtgi_hip_tracer *h, const rtgi::SceneView &scene) {
 int sort_rays(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint32_t n, hipStream_t stream) {
 	if (n > h->sort_cap) {
 		if (h->d_sort) (void)hipFree(h->d_sort);
-		if (h->d_sort_temp) (void)hipFree(h->d_sort_temp);
 		h->d_sort = nullptr;
-		h->d_sort_temp = nullptr;
 		h->sort_cap = 0;
 		const size_t cap = (size_t)n + n / 8 + 1024;
 		HIP_TRY(h, hipMalloc((void **)&h->d_sort, 4 * cap * sizeof(uint32_t)));
-		size_t temp = 0;
-		HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(nullptr, temp, h->d_sort, h->d_sort + cap, h->d_sort + 2 * cap,
-		                                            h->d_sort + 3 * cap, (int)cap, 0, 30, stream));
-		HIP_TRY(h, hipMalloc(&h->d_sort_temp, temp));
-		h->sort_temp_bytes = temp;
 		h->sort_cap = cap;
 	}
 	const size_t cap = h->sort_cap;
+	uint32_t *keys_in = h->d_sort, *keys_out = h->d_sort + cap, *index_in = h->d_sort + 2 * cap, *index_out = h->d_sort + 3 * cap;
+	// the sort's scratch size depends on the item count (the library picks its algorithm by size): ask for this n
+	size_t temp = 0;
+	HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(nullptr, temp, keys_in, keys_out, index_in, index_out, (int)n, h->sort_begin_bit, 32, stream));
+	if (temp > h->sort_temp_bytes) {
+		if (h->d_sort_temp) (void)hipFree(h->d_sort_temp);
+		h->d_sort_temp = nullptr;
+		h->sort_temp_bytes = 0;
+		HIP_TRY(h, hipMalloc(&h->d_sort_temp, temp + temp / 4 + 256));
+		h->sort_temp_bytes = temp + temp / 4 + 256;
+	}
 	rtgi_dev::KeyArgs k;
 	k.rays = (const float4 *)d_rays;
-	k.keys = h->d_sort;
-	k.index = h->d_sort + 2 * cap;
-	for (int c = 0; c < 3; ++c) k.lo[c] = h->scene_lo[c], k.inv_extent[c] = h->scene_inv_extent[c];
+	k.keys = keys_in;
+	k.index = index_in;
+	for (int c = 0; c < 3; ++c) k.lo[c] = h->scene_lo[c], k.hi[c] = h->scene_hi[c], k.inv_extent[c] = h->scene_inv_extent[c];
+	k.class_bits = h->class_bits;
+	k.span_max_bits = h->d_counter + 8 * rtgi_dev::COUNTER_STRIDE + 12;
 	k.n = n;
+	HIP_TRY(h, hipMemsetAsync(k.span_max_bits, 0, sizeof(uint32_t), stream));
+	hipLaunchKernelGGL(rtgi_dev::ray_span_max_kernel, dim3(std::min<uint32_t>((n + 255) / 256, 512u)), dim3(256), 0, stream, k);
+	HIP_TRY(h, debug_sync(h, "ray_span_max_kernel", stream));
 	hipLaunchKernelGGL(rtgi_dev::ray_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, k);
-	size_t temp = h->sort_temp_bytes;
-	HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(h->d_sort_temp, temp, h->d_sort, h->d_sort + cap, h->d_sort + 2 * cap,
-	                                            h->d_sort + 3 * cap, (int)n, 0, 30, stream));
+	HIP_TRY(h, debug_sync(h, "ray_keys_kernel", stream));
+	size_t temp_size = h->sort_temp_bytes;
+	HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(h->d_sort_temp, temp_size, keys_in, keys_out, index_in, index_out, (int)n,
+	                                            h->sort_begin_bit, 32, stream));
+	HIP_TRY(h, debug_sync(h, "radix sort", stream));
+	hipLaunchKernelGGL(rtgi_dev::segment_bounds_kernel, dim3(1), dim3(64), 0, stream, keys_out, n,
+	                   h->d_counter + 8 * rtgi_dev::COUNTER_STRIDE);
+	HIP_TRY(h, debug_sync(h, "segment_bounds_kernel", stream));
 	return RTGI_OK;
 }
 
@@ -204,18 +240,46 @@ int launch(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint32_t n, void *d_out, 
 	a.node_bytes = h->node_bytes;
 	a.tri_bytes = h->tri_bytes;
 	a.root_ref = h->root_ref;
+#ifdef RTGI_DIAG
+	static unsigned long long *d_diag = nullptr;
+	auto diag_reset = [&]() -> hipError_t {
+		unsigned long long init[16] = {0};
+		init[8] = init[10] = ~0ull;
+		return hipMemcpy(d_diag, init, sizeof(init), hipMemcpyHostToDevice);
+	};
+	if (!d_diag) {
+		HIP_TRY(h, hipMalloc((void **)&d_diag, 128));
+		HIP_TRY(h, diag_reset());
+	}
+	a.diag = d_diag;
+	if (getenv("RTGI_DIAG_PRINT")) {
+		unsigned long long v[16];
+		HIP_TRY(h, hipDeviceSynchronize());
+		HIP_TRY(h, hipMemcpy(v, d_diag, 128, hipMemcpyDeviceToHost));
+		HIP_TRY(h, diag_reset());
+		if (v[7])
+			fprintf(stderr, "diag(prev launch): inner iters fed %llu (%.1f%% lanes) | dry %llu (%.1f%% lanes) | refills %llu outer %llu | wall %.3f ms, supply dry at %.3f..%.3f ms, mean wave life %.3f ms\n",
+			        v[0], v[0] ? 100.0 * v[1] / (64.0 * v[0]) : 0.0, v[2], v[2] ? 100.0 * v[3] / (64.0 * v[2]) : 0.0, v[6], v[7],
+			        (v[9] - v[8]) * 1e-5, (v[10] - v[8]) * 1e-5, (v[11] - v[8]) * 1e-5, v[12] * 1e-5 / (double)(h->grid_blocks * 4));
+	}
+#endif
 	a.refill_min = h->refill_min;
 	a.leaf_min = h->leaf_min;
 	uint32_t blocks = (n + BLOCK - 1) / BLOCK;
 	if (blocks > h->grid_blocks) blocks = h->grid_blocks;
 	a.spill_stride = blocks * BLOCK;
 	a.order = nullptr;
+	a.seg_bounds = nullptr;
 	if (h->reorder && n >= h->reorder_min) {
 		int rc = sort_rays(h, d_rays, n, stream);
 		if (rc) return rc;
 		a.order = h->d_sort + 3 * h->sort_cap;
+		if (h->octant_segments) {
+			a.seg_bounds = h->d_counter + 8 * rtgi_dev::COUNTER_STRIDE;  // one part per direction octant
+			a.n_segments = 8;
+		} else
+			a.n_segments = 1;  // the sorted order (long rays first) is global; all waves draw from its front
 	}
-	HIP_TRY(h, hipMemsetAsync(h->d_counter, 0, 8 * rtgi_dev::COUNTER_STRIDE * sizeof(uint32_t), stream));
 	hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 	if (h->profiling && h->events_used < 4096) {
 		if (h->events_used == h->events.size()) {
@@ -230,6 +294,7 @@ int launch(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint32_t n, void *d_out, 
 		HIP_TRY(h, hipEventRecord(ev_start, stream));
 	}
 	const bool deep = h->spill_levels > 0;  // the tree is deeper than the LDS part of the stack
+	HIP_TRY(h, hipMemsetAsync(h->d_counter, 0, 8 * rtgi_dev::COUNTER_STRIDE * sizeof(uint32_t), stream));
 	if (d_counts && deep)
 		hipLaunchKernelGGL((trace_kernel<ANY, true, true>), dim3(blocks), dim3(BLOCK), 0, stream, a);
 	else if (d_counts)
@@ -239,7 +304,7 @@ int launch(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint32_t n, void *d_out, 
 	else
 		hipLaunchKernelGGL((trace_kernel<ANY, false, false>), dim3(blocks), dim3(BLOCK), 0, stream, a);
 	if (ev_stop) HIP_TRY(h, hipEventRecord(ev_stop, stream));
-	HIP_TRY(h, hipGetLastError());
+	HIP_TRY(h, debug_sync(h, ANY ? "trace_kernel any_hit" : "trace_kernel closest_hit", stream));
 	return RTGI_OK;
 }
 

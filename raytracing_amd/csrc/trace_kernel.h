@@ -41,6 +41,7 @@ struct TraceArgs {
 	const void *tris;       // 48 B per leaf-order slot
 	const float4 *rays;     // 32 B per ray: o.xyz d.x | d.yz t_min t_max
 	const uint32_t *order;  // optional: the i-th ray to trace is rays[order[i]] (spatially sorted batches)
+	const uint32_t *seg_bounds;  // optional: n_segments + 1 positions cutting the (sorted) batch; else equal parts
 	float4 *hits;           // closest_hit output
 	uint8_t *occluded;      // any_hit output
 	uint32_t *counts;       // optional: 2 per ray
@@ -53,6 +54,9 @@ struct TraceArgs {
 	int32_t root_ref;
 	int32_t refill_min;     // refill a wave once this many lanes are idle
 	int32_t leaf_min;       // leave the inner-node loop once this many lanes have left it
+#ifdef RTGI_DIAG
+	unsigned long long *diag;  // diagnostic build only: 8 counters summed over all waves
+#endif
 };
 
 // Single-instruction min / max for values that cannot be NaN. (fminf/fmaxf would first canonicalise every
@@ -93,6 +97,7 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 	const int lane = tid & 63;
 	const uint32_t gl = blockIdx.x * BLOCK + tid;
 
+	const uint32_t n_rays = a.n_rays;
 	const __amdgpu_buffer_rsrc_t node_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.nodes), 0, (int)a.node_bytes, 0x00020000);
 	const __amdgpu_buffer_rsrc_t tri_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.tris), 0, (int)a.tri_bytes, 0x00020000);
 
@@ -143,16 +148,28 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 			cur = pop();
 	};
 
+#ifdef RTGI_DIAG
+	const unsigned long long dg_t0 = __builtin_amdgcn_s_memrealtime();
+	unsigned long long dg_t_dry = 0;
+	unsigned long long dg_it_more = 0, dg_ln_more = 0, dg_it_drain = 0, dg_ln_drain = 0, dg_it_leaf = 0, dg_ln_leaf = 0, dg_refills = 0, dg_outer = 0;
+#endif
 	for (;;) {
+#ifdef RTGI_DIAG
+		++dg_outer;
+#endif
 		// ---- hand new rays to idle lanes --------------------------------------------------------------
 		const unsigned long long idle = __ballot(cur == IDLE);
 		if (more && __popcll(idle) >= a.refill_min) {
+#ifdef RTGI_DIAG
+			++dg_refills;
+#endif
 			const uint32_t want = (uint32_t)__popcll(idle);
 			const int leader = (int)__ffsll((long long)idle) - 1;
 			uint32_t first = 0, avail = 0;
 			for (;;) {  // draw from this wave's segment; when it is used up, move on to the next one
-				const uint32_t seg_lo = (uint32_t)((uint64_t)a.n_rays * seg / a.n_segments);
-				const uint32_t seg_len = (uint32_t)((uint64_t)a.n_rays * (seg + 1) / a.n_segments) - seg_lo;
+				const uint32_t seg_lo = a.seg_bounds ? a.seg_bounds[seg] : (uint32_t)((uint64_t)n_rays * seg / a.n_segments);
+				const uint32_t seg_hi = a.seg_bounds ? a.seg_bounds[seg + 1] : (uint32_t)((uint64_t)n_rays * (seg + 1) / a.n_segments);
+				const uint32_t seg_len = seg_hi - seg_lo;
 				uint32_t base = 0;
 				if (lane == leader) base = atomicAdd(a.ray_counter + seg * COUNTER_STRIDE, want);
 				base = __shfl(base, leader);
@@ -163,13 +180,17 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 				}
 				if (++segs_done == a.n_segments) {
 					more = false;
+#ifdef RTGI_DIAG
+					dg_t_dry = __builtin_amdgcn_s_memrealtime();
+#endif
 					break;
 				}
 				seg = seg + 1 == a.n_segments ? 0 : seg + 1;
 			}
 			const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-			if (cur == IDLE && rank < avail) {
-				const uint32_t mine = a.order ? a.order[first + rank] : first + rank;
+			// (an index from the order array is trusted only as far as the batch goes)
+			const uint32_t mine = (rank < avail) ? (a.order ? a.order[first + rank] : first + rank) : 0xffffffffu;
+			if (cur == IDLE && mine < n_rays) {
 				const float4 q0 = a.rays[2 * (size_t)mine], q1 = a.rays[2 * (size_t)mine + 1];
 				ox = q0.x, oy = q0.y, oz = q0.z;
 				dx = q0.w, dy = q1.x, dz = q1.y;
@@ -179,12 +200,12 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 				plain = usable(ix) && usable(iy) && usable(iz) && __builtin_isfinite(ox) && __builtin_isfinite(oy) &&
 				        __builtin_isfinite(oz) && t_min == t_min && t_max == t_max && t_max != __builtin_inff();
 				lim0 = next_up(t_max);
-				lim = ANY ? lim0 : __builtin_fminf(FLT_MAX, lim0);
 				ray_id = mine;
 				best_t = FLT_MAX, best_b = 0.0f, best_g = 0.0f, best_ref = 0;
 				n_inner = n_tri = 0;
 				cur = a.root_ref;
 				sp = 0;
+				lim = ANY ? lim0 : __builtin_fminf(best_t, lim0);
 			}
 		}
 		const unsigned long long busy = __ballot(cur != IDLE);
@@ -202,6 +223,10 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 			for (;;) {
 				const bool at_inner = cur >= 0;
 				if ((int)__popcll(__ballot(at_inner)) <= keep_going) break;
+#ifdef RTGI_DIAG
+				if (more) ++dg_it_more, dg_ln_more += __popcll(__ballot(at_inner));
+				else ++dg_it_drain, dg_ln_drain += __popcll(__ballot(at_inner));
+#endif
 				if (at_inner) {
 					const int voff = cur << 6;
 					const u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(node_rsrc, voff, 0, 0);
@@ -268,6 +293,9 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 			int voff = (int)(~cur) * 48;
 			bool done = false;
 			for (;;) {
+#ifdef RTGI_DIAG
+				++dg_it_leaf, dg_ln_leaf += __popcll(__ballot(true));
+#endif
 				const u32x4 t0 = __builtin_amdgcn_raw_buffer_load_b128(tri_rsrc, voff, 0, 0);
 				const u32x4 t1 = __builtin_amdgcn_raw_buffer_load_b128(tri_rsrc, voff + 16, 0, 0);
 				const u32x4 t2 = __builtin_amdgcn_raw_buffer_load_b128(tri_rsrc, voff + 32, 0, 0);
@@ -309,17 +337,31 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 				advance();
 		}
 	}
+#ifdef RTGI_DIAG
+	if (lane == 0 && a.diag) {
+		atomicAdd(a.diag + 0, dg_it_more), atomicAdd(a.diag + 1, dg_ln_more), atomicAdd(a.diag + 2, dg_it_drain);
+		atomicAdd(a.diag + 3, dg_ln_drain), atomicAdd(a.diag + 4, dg_it_leaf), atomicAdd(a.diag + 5, dg_ln_leaf);
+		atomicAdd(a.diag + 6, dg_refills), atomicAdd(a.diag + 7, dg_outer);
+		const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+		atomicMin(a.diag + 8, dg_t0), atomicMax(a.diag + 9, t_end);
+		if (dg_t_dry) atomicMin(a.diag + 10, dg_t_dry), atomicMax(a.diag + 11, dg_t_dry);
+		atomicAdd(a.diag + 12, t_end - dg_t0);
+	}
+#endif
+
 }
 
-// Sort key of a ray: direction octant (3 bits) above a 27-bit Morton code of the origin inside the scene's
-// bounds. Rays that start close together and head the same way end up in the same waves and walk the same
+// Sort key of a ray: length class (2 bits), direction octant (3 bits), 27-bit Morton code of the origin inside
+// the scene's bounds. Rays that start close together and head the same way end up in the same waves and walk the same
 // nodes, which the caches reward; the order of tracing does not change any ray's result.
 struct KeyArgs {
 	const float4 *rays;
 	uint32_t *keys;
 	uint32_t *index;
-	float lo[3], inv_extent[3];
+	float lo[3], hi[3], inv_extent[3];
 	uint32_t n;
+	uint32_t class_bits;      // 0..4: 2^class_bits length classes
+	uint32_t *span_max_bits;  // float bits of the largest span in the batch
 };
 __device__ __forceinline__ uint32_t spread3(uint32_t v) {  // 9 bits -> every third bit
 	v = (v | (v << 16)) & 0x030000FFu;
@@ -328,6 +370,37 @@ __device__ __forceinline__ uint32_t spread3(uint32_t v) {  // 9 bits -> every th
 	v = (v | (v << 2)) & 0x09249249u;
 	return v;
 }
+// How far a ray can travel inside the scene's bounds, clipped to its own [t_min, t_max]: an upper bound on
+// its traversal work that costs one slab test. <= 0 or NaN for rays that miss the scene.
+__device__ __forceinline__ float ray_span(const KeyArgs &a, const float4 q0, const float4 q1) {
+	const float dir[3] = {q0.w, q1.x, q1.y}, org[3] = {q0.x, q0.y, q0.z};
+	float t_in = q1.z, t_out = q1.w;
+	for (int k = 0; k < 3; ++k) {
+		const float inv = 1.0f / dir[k];
+		const float ta = (a.lo[k] - org[k]) * inv, tb = (a.hi[k] - org[k]) * inv;
+		t_in = __builtin_fmaxf(t_in, __builtin_fminf(ta, tb));
+		t_out = __builtin_fminf(t_out, __builtin_fmaxf(ta, tb));
+	}
+	return t_out - t_in;
+}
+
+// Largest span of the batch (float bits of a non-negative number order like the number).
+__global__ __launch_bounds__(256) void ray_span_max_kernel(KeyArgs a) {
+	__shared__ float s_part[4];
+	float span = 0.0f;
+	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < a.n; i += gridDim.x * 256u) {  // few blocks: few atomics
+		const float v = ray_span(a, a.rays[2 * (size_t)i], a.rays[2 * (size_t)i + 1]);
+		if (v == v && v > 0.0f && v < 3.0e38f) span = __builtin_fmaxf(span, v);
+	}
+	for (int off = 32; off > 0; off >>= 1) span = __builtin_fmaxf(span, __shfl_xor(span, off));
+	if ((threadIdx.x & 63u) == 0) s_part[threadIdx.x >> 6] = span;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		span = __builtin_fmaxf(__builtin_fmaxf(s_part[0], s_part[1]), __builtin_fmaxf(s_part[2], s_part[3]));
+		if (span > 0.0f) atomicMax(a.span_max_bits, __float_as_uint(span));
+	}
+}
+
 __global__ __launch_bounds__(256) void ray_keys_kernel(KeyArgs a) {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= a.n) return;
@@ -339,8 +412,38 @@ __global__ __launch_bounds__(256) void ray_keys_kernel(KeyArgs a) {
 	const uint32_t morton = spread3(cell(q0.x, a.lo[0], a.inv_extent[0])) | (spread3(cell(q0.y, a.lo[1], a.inv_extent[1])) << 1) |
 	                        (spread3(cell(q0.z, a.lo[2], a.inv_extent[2])) << 2);
 	const uint32_t octant = (q0.w < 0.0f ? 1u : 0u) | (q1.x < 0.0f ? 2u : 0u) | (q1.y < 0.0f ? 4u : 0u);
-	a.keys[i] = (octant << 27) | morton;
+	// Length class, longest first, in equal steps up to the batch's largest span. A launch ends when its last
+	// ray does, so rays that can be long are started first and the end of the launch is left to rays that
+	// must be short.
+	const float span_max = __uint_as_float(*a.span_max_bits);
+	const uint32_t n_cls = 1u << a.class_bits;
+	const float rel = span_max > 0.0f ? ray_span(a, q0, q1) / span_max * (float)n_cls : 0.0f;
+	const uint32_t step = (uint32_t)__builtin_fminf(__builtin_fmaxf(rel == rel ? rel : 0.0f, 0.0f), (float)(n_cls - 1u));
+	const uint32_t cls = n_cls - 1u - step;
+	// octant | class | Morton (the low Morton bits give way to the class bits)
+	a.keys[i] = (octant << 29) | (cls << (29u - a.class_bits)) | (morton >> (a.class_bits > 2u ? a.class_bits - 2u : 0u) << (a.class_bits < 2u ? 2u - a.class_bits : 0u));
 	a.index[i] = i;
+}
+
+// Positions in the sorted key array where the direction octant changes: the 8 parts of the batch that the 8
+// XCDs start on (bounds[8] = n).
+__global__ void segment_bounds_kernel(const uint32_t *sorted_keys, uint32_t n, uint32_t *bounds) {
+	const uint32_t s = threadIdx.x;
+	if (s > 8) return;
+	if (s == 8) {
+		bounds[8] = n;
+		return;
+	}
+	const uint32_t want = s << 29;
+	uint32_t lo = 0, hi = n;
+	while (lo < hi) {  // first position whose key is >= want
+		const uint32_t mid = lo + (hi - lo) / 2;
+		if (sorted_keys[mid] < want)
+			lo = mid + 1;
+		else
+			hi = mid;
+	}
+	bounds[s] = lo;
 }
 
 }  // namespace rtgi_dev

@@ -200,6 +200,27 @@ def test_batch_sizes_and_argument_checks():
     assert rc == -1
 
 
+def test_large_batches_are_reordered_without_changing_results():
+    # batches of 2^16 rays and more are sorted (direction octant, length class, Morton code of the origin) before
+    # tracing and each XCD starts on its own part; hits, any-hit bytes and per-ray counts must not notice
+    import torch
+    for scene, cmds in ((scenes.soup(20000, seed=8, size=0.2), ()), (scenes.skewed(30000, seed=6), ("sm",))):
+        pos, tri, _ = scene
+        t = tracer.HipBvhTracer(layout="indexed")
+        _configure(t, cmds)
+        t.build(pos, tri)
+        o = _oracle_for(pos, tri, "indexed", False, cmds)
+        rays = _mixed_rays(pos, 300000, seed=21)
+        want, want_counts = o.closest_hit(rays, counts=True)
+        want_any, want_any_counts = o.any_hit(rays, counts=True)
+        assert_hits_equal(t.closest_hit(rays), want, "reordered closest_hit")
+        assert t.interprete("hip", "reorder off")
+        assert_hits_equal(t.closest_hit(rays), want, "closest_hit in given order")
+        assert t.interprete("hip", "reorder on")
+        assert (t.any_hit(rays) == want_any).all()
+        _check_device_path(t, rays, want, want_counts, want_any, want_any_counts)
+
+
 def test_upload_of_a_foreign_tree():
     pos, tri, _ = scenes.soup(8000, seed=6)
     o = orc.Bbvh(pos, tri, layout="indexed", split="sah", planes=8)
