@@ -73,8 +73,9 @@ void rtgi_hip_destroy(rtgi_hip_tracer *h);
 
 /* ray_tracer::interprete(command, in), bvh2.cpp:503-555: `args` is the rest of the command line.
  * Handles "bvh om | sm | sah N | triangles single | triangles multiple N | statistics | export D file" and
- * the backend's own "hip reorder on | off" (sort large ray batches spatially before tracing; default on;
- * results do not depend on it).
+ * the backend's own "hip reorder auto | on | off" (trace batches of 65536 rays and more in a spatially sorted
+ * order: where the scene makes incoherent rays expensive, always, never; default auto; results do not
+ * depend on it).
  * Returns 1 if the command was consumed, 0 if it is not for this tracer, RTGI_ERR_SYNTAX if it was
  * recognised but malformed (the reference prints an error and still reports "consumed"). */
 int rtgi_hip_interprete(rtgi_hip_tracer *h, const char *command, const char *args);
@@ -104,6 +105,11 @@ uint32_t rtgi_hip_num_nodes(const rtgi_hip_tracer *h);
 uint32_t rtgi_hip_num_index(const rtgi_hip_tracer *h); /* leaf-order slots (> n_triangles with esc) */
 uint32_t rtgi_hip_root(const rtgi_hip_tracer *h);
 uint32_t rtgi_hip_depth(const rtgi_hip_tracer *h);     /* deepest leaf, root = 0 */
+/* What "hip reorder auto" decides by (no counterpart in the reference): the mean number of inner nodes a
+ * closest_hit ray pops when it starts on a random triangle in a random direction, measured on the GPU at
+ * build / upload with 32768 seeded rays. Batches are sorted before tracing where this exceeds 120.
+ * 0 for host-only handles and scenes of fewer than 4096 leaf slots. */
+float rtgi_hip_incoherent_ray_cost(const rtgi_hip_tracer *h);
 int rtgi_hip_get_nodes(const rtgi_hip_tracer *h, rtgi_node56 *out);
 /* Leaf-order list of ORIGINAL triangle ids (index[] of the indexed layout; for the flat layout the
  * permutation new_tris[i] = old_tris[out[i]] of bvh2.cpp:176-179). */

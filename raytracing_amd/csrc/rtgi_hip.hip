@@ -30,6 +30,7 @@ namespace {
 // host side
 // ---------------------------------------------------------------------------------------------------
 thread_local std::string g_create_error;
+constexpr size_t PROBE_RAYS = 1u << 15;
 
 }  // namespace
 
@@ -51,18 +52,18 @@ struct rtgi_hip_tracer {
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
 	size_t events_used = 0;
 
-	// spatial reordering of ray batches ("hip reorder on|off")
-	bool reorder = true;
+	// spatial reordering of ray batches ("hip reorder auto|on|off")
+	int reorder = 2;                  // 0 off, 1 always, 2 by the scene (see probe_pops)
 	uint32_t reorder_min = 1u << 16;  // smaller batches are traced as they come
-	// All 32 key bits are sorted: with a sub-range of bits (begin_bit = 8) rocPRIM's radix sort of ROCm 7.2 returns
-	// wrong permutations for batches of up to a few 100 k items (scripts/ubench/sort_check.hip).
-	int sort_begin_bit = 0;
-	bool octant_segments = true;
-	uint32_t class_bits = 3;
 	float scene_lo[3] = {0, 0, 0}, scene_hi[3] = {1, 1, 1}, scene_inv_extent[3] = {1, 1, 1};
 	uint32_t *d_sort = nullptr;  // keys in, keys out, index in, index out
 	void *d_sort_temp = nullptr;
 	size_t sort_cap = 0, sort_temp_bytes = 0;
+	// "auto": sorting pays where incoherent rays are expensive. probe_pops is the mean number of inner nodes a
+	// closest_hit ray pops when it starts on a random triangle in a random direction, measured at upload.
+	float probe_pops = 0.0f;
+	float reorder_min_pops = 120.0f;
+	std::vector<rtgi_ray> probe_rays;
 	uint32_t node_bytes = 0, tri_bytes = 0;
 	int refill_min = 16, leaf_min = 8;
 	uint32_t n_segments = 8;
@@ -148,11 +149,38 @@ int upload(rtgi_hip_tracer *h, const rtgi::SceneView &scene) {
 		h->scene_hi[k] = hi[k];
 		h->scene_inv_extent[k] = hi[k] > lo[k] ? 1.0f / (hi[k] - lo[k]) : 0.0f;
 	}
-	if (const char *e = getenv("RTGI_HIP_REORDER")) h->reorder = atoi(e) != 0;
-	if (const char *e = getenv("RTGI_HIP_OCTANT_SEGMENTS")) h->octant_segments = atoi(e) != 0;
-	if (const char *e = getenv("RTGI_HIP_CLASS_BITS")) h->class_bits = (uint32_t)std::max(0, std::min(4, atoi(e)));
+	if (const char *e = getenv("RTGI_HIP_REORDER")) h->reorder = std::max(0, std::min(2, atoi(e)));
 	h->root_ref = flat.root_ref;
 	h->built = true;
+	// probe rays for the reorder policy: from random points of random triangles into random directions
+	h->probe_rays.clear();
+	h->probe_pops = 0.0f;
+	if (flat.n_slots >= 4096) {
+		uint64_t state = 0x9E3779B97F4A7C15ull;
+		auto uniform = [&]() {  // 24 random bits -> [0, 1)
+			state = state * 6364136223846793005ull + 1442695040888963407ull;
+			return (float)((state >> 40) & 0xFFFFFFu) * (1.0f / 16777216.0f);
+		};
+		h->probe_rays.resize(PROBE_RAYS);
+		for (rtgi_ray &r : h->probe_rays) {
+			const size_t slot = std::min<size_t>((size_t)(uniform() * (float)flat.n_slots), flat.n_slots - 1);
+			const float *t = &flat.tris[12 * slot];  // A | A - B | A - C
+			float u = uniform(), v = uniform();
+			if (u + v > 1.0f) u = 1.0f - u, v = 1.0f - v;
+			float d[3], len2;
+			do {  // uniform direction: a point in the unit ball, normalised
+				len2 = 0.0f;
+				for (int k = 0; k < 3; ++k) d[k] = 2.0f * uniform() - 1.0f, len2 += d[k] * d[k];
+			} while (len2 > 1.0f || len2 < 1e-4f);
+			const float inv = 1.0f / std::sqrt(len2);
+			for (int k = 0; k < 3; ++k) {
+				r.o[k] = t[k] - u * t[4 + k] - v * t[8 + k];
+				r.d[k] = d[k] * inv;
+			}
+			r.t_min = 1e-4f;
+			r.t_max = FLT_MAX;
+		}
+	}
 	return RTGI_OK;
 }
 
@@ -170,8 +198,8 @@ hipError_t debug_sync(rtgi_hip_tracer *h, const char *stage, hipStream_t stream)
 	return e;
 }
 
-// Sorts the batch by (direction octant, Morton code of the origin); leaves the permutation in the fourth
-// quarter of d_sort. Buffers grow on demand and are kept.
+// Sorts the batch by the key of ray_keys_kernel: the permutation ends up in the fourth quarter of d_sort, the
+// octant boundaries behind the ray counters. Buffers grow on demand and are kept.
 int sort_rays(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint32_t n, hipStream_t stream) {
 	if (n > h->sort_cap) {
 		if (h->d_sort) (void)hipFree(h->d_sort);
@@ -185,7 +213,7 @@ int sort_rays(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint32_t n, hipStream_
 	uint32_t *keys_in = h->d_sort, *keys_out = h->d_sort + cap, *index_in = h->d_sort + 2 * cap, *index_out = h->d_sort + 3 * cap;
 	// the sort's scratch size depends on the item count (the library picks its algorithm by size): ask for this n
 	size_t temp = 0;
-	HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(nullptr, temp, keys_in, keys_out, index_in, index_out, (int)n, h->sort_begin_bit, 32, stream));
+	HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(nullptr, temp, keys_in, keys_out, index_in, index_out, (int)n, 0, rtgi_dev::KEY_BITS, stream));
 	if (temp > h->sort_temp_bytes) {
 		if (h->d_sort_temp) (void)hipFree(h->d_sort_temp);
 		h->d_sort_temp = nullptr;
@@ -197,20 +225,22 @@ int sort_rays(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint32_t n, hipStream_
 	k.rays = (const float4 *)d_rays;
 	k.keys = keys_in;
 	k.index = index_in;
-	for (int c = 0; c < 3; ++c) k.lo[c] = h->scene_lo[c], k.hi[c] = h->scene_hi[c], k.inv_extent[c] = h->scene_inv_extent[c];
-	k.class_bits = h->class_bits;
-	k.span_max_bits = h->d_counter + 8 * rtgi_dev::COUNTER_STRIDE + 12;
+	float diag2 = 0.0f;
+	for (int c = 0; c < 3; ++c) {
+		k.lo[c] = h->scene_lo[c], k.hi[c] = h->scene_hi[c], k.inv_extent[c] = h->scene_inv_extent[c];
+		diag2 += (h->scene_hi[c] - h->scene_lo[c]) * (h->scene_hi[c] - h->scene_lo[c]);
+	}
+	k.inv_diagonal = diag2 > 0.0f ? 1.0f / std::sqrt(diag2) : 0.0f;
 	k.n = n;
-	HIP_TRY(h, hipMemsetAsync(k.span_max_bits, 0, sizeof(uint32_t), stream));
-	hipLaunchKernelGGL(rtgi_dev::ray_span_max_kernel, dim3(std::min<uint32_t>((n + 255) / 256, 512u)), dim3(256), 0, stream, k);
-	HIP_TRY(h, debug_sync(h, "ray_span_max_kernel", stream));
 	hipLaunchKernelGGL(rtgi_dev::ray_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, k);
 	HIP_TRY(h, debug_sync(h, "ray_keys_kernel", stream));
+	// Only the KEY_BITS low bits hold the key. (Sorting a bit range that does not start at bit 0 returned wrong
+	// permutations for batches of up to a few 100 k items with rocPRIM of ROCm 7.2.)
 	size_t temp_size = h->sort_temp_bytes;
-	HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(h->d_sort_temp, temp_size, keys_in, keys_out, index_in, index_out, (int)n,
-	                                            h->sort_begin_bit, 32, stream));
+	HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(h->d_sort_temp, temp_size, keys_in, keys_out, index_in, index_out, (int)n, 0,
+	                                            rtgi_dev::KEY_BITS, stream));
 	HIP_TRY(h, debug_sync(h, "radix sort", stream));
-	hipLaunchKernelGGL(rtgi_dev::segment_bounds_kernel, dim3(1), dim3(64), 0, stream, keys_out, n,
+	hipLaunchKernelGGL(rtgi_dev::segment_bounds_kernel, dim3(1), dim3(512), 0, stream, keys_out, n,
 	                   h->d_counter + 8 * rtgi_dev::COUNTER_STRIDE);
 	HIP_TRY(h, debug_sync(h, "segment_bounds_kernel", stream));
 	return RTGI_OK;
@@ -270,15 +300,12 @@ int launch(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint32_t n, void *d_out, 
 	a.spill_stride = blocks * BLOCK;
 	a.order = nullptr;
 	a.seg_bounds = nullptr;
-	if (h->reorder && n >= h->reorder_min) {
+	if ((h->reorder == 1 || (h->reorder == 2 && h->probe_pops > h->reorder_min_pops)) && n >= h->reorder_min) {
 		int rc = sort_rays(h, d_rays, n, stream);
 		if (rc) return rc;
 		a.order = h->d_sort + 3 * h->sort_cap;
-		if (h->octant_segments) {
-			a.seg_bounds = h->d_counter + 8 * rtgi_dev::COUNTER_STRIDE;  // one part per direction octant
-			a.n_segments = 8;
-		} else
-			a.n_segments = 1;  // the sorted order (long rays first) is global; all waves draw from its front
+		a.seg_bounds = h->d_counter + 8 * rtgi_dev::COUNTER_STRIDE;  // one part per direction octant
+		a.n_segments = 8;
 	}
 	hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 	if (h->profiling && h->events_used < 4096) {
@@ -344,6 +371,35 @@ int trace_host(rtgi_hip_tracer *h, const rtgi_ray *rays, uint32_t n, void *out) 
 	return RTGI_OK;
 }
 
+// Traces the probe rays of upload() in the order they come and stores the mean number of inner nodes popped.
+int probe_scene(rtgi_hip_tracer *h) {
+	if (h->device < 0 || h->probe_rays.empty()) return RTGI_OK;
+	const uint32_t n = (uint32_t)h->probe_rays.size();
+	int rc = ensure_stage(h, (size_t)n * sizeof(rtgi_ray), (size_t)n * sizeof(rtgi_hit));
+	if (rc) return rc;
+	uint32_t *d_counts = nullptr;
+	HIP_TRY(h, hipMalloc((void **)&d_counts, (size_t)n * 2 * sizeof(uint32_t)));
+	std::vector<uint32_t> counts((size_t)n * 2);
+	hipError_t e = hipMemcpy(h->d_stage_rays, h->probe_rays.data(), (size_t)n * sizeof(rtgi_ray), hipMemcpyHostToDevice);
+	if (e == hipSuccess) {
+		const int reorder = h->reorder;
+		h->reorder = 0;
+		rc = launch<false>(h, (const rtgi_ray *)h->d_stage_rays, n, h->d_stage_out, d_counts, nullptr);
+		h->reorder = reorder;
+		if (rc == RTGI_OK) e = hipMemcpy(counts.data(), d_counts, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost);
+	}
+	(void)hipFree(d_counts);
+	h->probe_rays.clear();
+	h->probe_rays.shrink_to_fit();
+	if (rc) return rc;
+	HIP_TRY(h, e);
+	double pops = 0.0;
+	for (uint32_t i = 0; i < n; ++i) pops += counts[2 * (size_t)i];
+	h->probe_pops = (float)(pops / n);
+	return RTGI_OK;
+}
+
+
 }  // namespace
 
 extern "C" {
@@ -405,8 +461,9 @@ int rtgi_hip_interprete(rtgi_hip_tracer *h, const char *command, const char *arg
 		if (value == "reorder") {
 			std::string onoff;
 			in >> onoff;
-			if (onoff != "on" && onoff != "off") return fail(h, RTGI_ERR_SYNTAX, "Syntax error, \"hip reorder\" requires on or off");
-			h->reorder = onoff == "on";
+			if (onoff != "on" && onoff != "off" && onoff != "auto")
+				return fail(h, RTGI_ERR_SYNTAX, "Syntax error, \"hip reorder\" requires auto, on or off");
+			h->reorder = onoff == "off" ? 0 : onoff == "on" ? 1 : 2;
 			return 1;
 		}
 		return fail(h, RTGI_ERR_SYNTAX, "Unknown hip subcommand " + value);
@@ -483,7 +540,8 @@ int rtgi_hip_build(rtgi_hip_tracer *h, const void *vertices, size_t vertex_strid
 	try {
 		if (!rtgi::build_tree(h->cfg, scene, tree, err)) return fail(h, RTGI_ERR_INVALID, err);
 		h->tree = std::move(tree);
-		return upload(h, scene);
+		int rc_upload = upload(h, scene);
+		return rc_upload ? rc_upload : probe_scene(h);
 	} catch (const std::bad_alloc &) {
 		return fail(h, RTGI_ERR_NOMEM, "out of host memory while building the BVH");
 	}
@@ -515,7 +573,8 @@ int rtgi_hip_upload_bvh(rtgi_hip_tracer *h, const rtgi_node56 *nodes, uint32_t n
 		}
 		if (!rtgi::validate_tree(tree, n_triangles, err)) return fail(h, RTGI_ERR_INVALID, err);
 		h->tree = std::move(tree);
-		return upload(h, scene);
+		int rc_upload = upload(h, scene);
+		return rc_upload ? rc_upload : probe_scene(h);
 	} catch (const std::bad_alloc &) {
 		return fail(h, RTGI_ERR_NOMEM, "out of host memory while taking over the BVH");
 	}
@@ -525,6 +584,7 @@ uint32_t rtgi_hip_num_nodes(const rtgi_hip_tracer *h) { return h ? (uint32_t)h->
 uint32_t rtgi_hip_num_index(const rtgi_hip_tracer *h) { return h ? (uint32_t)h->tree.order.size() : 0; }
 uint32_t rtgi_hip_root(const rtgi_hip_tracer *h) { return h ? h->tree.root : 0; }
 uint32_t rtgi_hip_depth(const rtgi_hip_tracer *h) { return h ? h->tree.depth : 0; }
+float rtgi_hip_incoherent_ray_cost(const rtgi_hip_tracer *h) { return h ? h->probe_pops : 0.0f; }
 int rtgi_hip_get_nodes(const rtgi_hip_tracer *h, rtgi_node56 *out) {
 	if (!h || !out) return RTGI_ERR_INVALID;
 	memcpy(out, h->tree.nodes.data(), h->tree.nodes.size() * sizeof(rtgi_node56));

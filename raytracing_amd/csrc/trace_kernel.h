@@ -5,9 +5,9 @@
 // closest_hit, its entry distance is below the closest t so far; triangles by Cramer's rule in the operation
 // order of libgi/intersect.h:43-57; slab test of libgi/intersect.h:204-236.
 //
-// One ray per lane, wave64, persistent workgroups. The kernel is bound by instruction issue, not by memory
-// (halving the resident waves costs a few percent), so the design goal is few wave-instructions per useful
-// lane-step:
+// One ray per lane, wave64, persistent workgroups. While rays are in supply the kernel is bound by the rate of
+// random 64-byte node fetches below L1, at the end of a launch by the latency of its longest rays; the
+// structure keeps lanes busy and instructions per useful lane-step few:
 //  * a wave refills finished lanes from a global ray counter instead of waiting for its slowest ray;
 //  * lanes that reach a leaf wait until a handful have gathered, then the (long) triangle code runs for all
 //    of them at once; per ray the order of node visits and triangle tests is unchanged;
@@ -351,23 +351,24 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 
 }
 
-// Sort key of a ray: length class (2 bits), direction octant (3 bits), 27-bit Morton code of the origin inside
-// the scene's bounds. Rays that start close together and head the same way end up in the same waves and walk the same
-// nodes, which the caches reward; the order of tracing does not change any ray's result.
+// ---- spatial ordering of a ray batch ---------------------------------------------------------------------
+// Rays that start close together and head the same way walk the same nodes, which the caches reward; the
+// order of tracing does not change any ray's result. A batch can therefore be traced through a permutation
+// sorted by a 24-bit key: direction octant (3 bits) | length class (3 bits, longest first) | Morton code of the
+// origin inside the scene's bounds (6 bits per axis).
+constexpr int KEY_BITS = 24;
 struct KeyArgs {
 	const float4 *rays;
 	uint32_t *keys;
 	uint32_t *index;
 	float lo[3], hi[3], inv_extent[3];
+	float inv_diagonal;
 	uint32_t n;
-	uint32_t class_bits;      // 0..4: 2^class_bits length classes
-	uint32_t *span_max_bits;  // float bits of the largest span in the batch
 };
-__device__ __forceinline__ uint32_t spread3(uint32_t v) {  // 9 bits -> every third bit
-	v = (v | (v << 16)) & 0x030000FFu;
-	v = (v | (v << 8)) & 0x0300F00Fu;
-	v = (v | (v << 4)) & 0x030C30C3u;
-	v = (v | (v << 2)) & 0x09249249u;
+__device__ __forceinline__ uint32_t spread3(uint32_t v) {  // 6 bits -> every third bit
+	v = (v | (v << 8)) & 0x0000F00Fu;
+	v = (v | (v << 4)) & 0x000C30C3u;
+	v = (v | (v << 2)) & 0x00249249u;
 	return v;
 }
 // How far a ray can travel inside the scene's bounds, clipped to its own [t_min, t_max]: an upper bound on
@@ -384,66 +385,47 @@ __device__ __forceinline__ float ray_span(const KeyArgs &a, const float4 q0, con
 	return t_out - t_in;
 }
 
-// Largest span of the batch (float bits of a non-negative number order like the number).
-__global__ __launch_bounds__(256) void ray_span_max_kernel(KeyArgs a) {
-	__shared__ float s_part[4];
-	float span = 0.0f;
-	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < a.n; i += gridDim.x * 256u) {  // few blocks: few atomics
-		const float v = ray_span(a, a.rays[2 * (size_t)i], a.rays[2 * (size_t)i + 1]);
-		if (v == v && v > 0.0f && v < 3.0e38f) span = __builtin_fmaxf(span, v);
-	}
-	for (int off = 32; off > 0; off >>= 1) span = __builtin_fmaxf(span, __shfl_xor(span, off));
-	if ((threadIdx.x & 63u) == 0) s_part[threadIdx.x >> 6] = span;
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		span = __builtin_fmaxf(__builtin_fmaxf(s_part[0], s_part[1]), __builtin_fmaxf(s_part[2], s_part[3]));
-		if (span > 0.0f) atomicMax(a.span_max_bits, __float_as_uint(span));
-	}
-}
-
 __global__ __launch_bounds__(256) void ray_keys_kernel(KeyArgs a) {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= a.n) return;
 	const float4 q0 = a.rays[2 * (size_t)i], q1 = a.rays[2 * (size_t)i + 1];
 	auto cell = [](float x, float lo, float inv) {
-		const float f = (x - lo) * inv * 511.0f;
-		return (uint32_t)__builtin_fminf(__builtin_fmaxf(f == f ? f : 0.0f, 0.0f), 511.0f);
+		const float f = (x - lo) * inv * 64.0f;
+		return (uint32_t)__builtin_fminf(__builtin_fmaxf(f == f ? f : 0.0f, 0.0f), 63.0f);
 	};
 	const uint32_t morton = spread3(cell(q0.x, a.lo[0], a.inv_extent[0])) | (spread3(cell(q0.y, a.lo[1], a.inv_extent[1])) << 1) |
 	                        (spread3(cell(q0.z, a.lo[2], a.inv_extent[2])) << 2);
 	const uint32_t octant = (q0.w < 0.0f ? 1u : 0u) | (q1.x < 0.0f ? 2u : 0u) | (q1.y < 0.0f ? 4u : 0u);
-	// Length class, longest first, in equal steps up to the batch's largest span. A launch ends when its last
-	// ray does, so rays that can be long are started first and the end of the launch is left to rays that
-	// must be short.
-	const float span_max = __uint_as_float(*a.span_max_bits);
-	const uint32_t n_cls = 1u << a.class_bits;
-	const float rel = span_max > 0.0f ? ray_span(a, q0, q1) / span_max * (float)n_cls : 0.0f;
-	const uint32_t step = (uint32_t)__builtin_fminf(__builtin_fmaxf(rel == rel ? rel : 0.0f, 0.0f), (float)(n_cls - 1u));
-	const uint32_t cls = n_cls - 1u - step;
-	// octant | class | Morton (the low Morton bits give way to the class bits)
-	a.keys[i] = (octant << 29) | (cls << (29u - a.class_bits)) | (morton >> (a.class_bits > 2u ? a.class_bits - 2u : 0u) << (a.class_bits < 2u ? 2u - a.class_bits : 0u));
+	// Length class, longest first, in eighths of the scene's diagonal. A launch ends when its last ray does,
+	// so rays that can be long are started first and the end of the launch is left to rays that must be short.
+	const float rel = ray_span(a, q0, q1) * a.inv_diagonal * 8.0f;
+	const uint32_t cls = 7u - (uint32_t)__builtin_fminf(__builtin_fmaxf(rel == rel ? rel : 0.0f, 0.0f), 7.0f);
+	a.keys[i] = (octant << 21) | (cls << 18) | morton;
 	a.index[i] = i;
 }
 
 // Positions in the sorted key array where the direction octant changes: the 8 parts of the batch that the 8
-// XCDs start on (bounds[8] = n).
-__global__ void segment_bounds_kernel(const uint32_t *sorted_keys, uint32_t n, uint32_t *bounds) {
-	const uint32_t s = threadIdx.x;
-	if (s > 8) return;
-	if (s == 8) {
-		bounds[8] = n;
-		return;
+// XCDs start on (bounds[8] = n). One wave per boundary; every step cuts the candidate range into 64 parts.
+__global__ __launch_bounds__(512) void segment_bounds_kernel(const uint32_t *sorted_keys, uint32_t n, uint32_t *bounds) {
+	const uint32_t s = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	const uint32_t want = s << 21;
+	uint32_t lo = 0, hi = n;  // the first position whose key is >= want lies in [lo, hi]
+	while (hi - lo > 0) {
+		const uint32_t step = (hi - lo + 63u) / 64u;
+		const uint32_t probe = lo + lane * step;  // lanes probe lo, lo + step, ...
+		const bool below = probe < hi && sorted_keys[probe] < want;
+		const unsigned long long m = __ballot(below);  // a prefix of the lanes, because the keys are sorted
+		const uint32_t k = (uint32_t)__popcll(m);
+		if (k == 0) {
+			hi = lo;
+		} else {
+			const uint32_t new_lo = lo + (k - 1u) * step + 1u;
+			hi = k < 64u && lo + k * step < hi ? lo + k * step : hi;
+			lo = new_lo;
+		}
 	}
-	const uint32_t want = s << 29;
-	uint32_t lo = 0, hi = n;
-	while (lo < hi) {  // first position whose key is >= want
-		const uint32_t mid = lo + (hi - lo) / 2;
-		if (sorted_keys[mid] < want)
-			lo = mid + 1;
-		else
-			hi = mid;
-	}
-	bounds[s] = lo;
+	if (lane == 0) bounds[s] = lo;
+	if (threadIdx.x == 0) bounds[8] = n;
 }
 
 }  // namespace rtgi_dev

@@ -24,6 +24,7 @@ LAYOUT = {"flat": 0, "indexed": 1}
 EXPORTS = [
     "rtgi_hip_device_count", "rtgi_hip_create", "rtgi_hip_destroy", "rtgi_hip_interprete", "rtgi_hip_build",
     "rtgi_hip_upload_bvh", "rtgi_hip_num_nodes", "rtgi_hip_num_index", "rtgi_hip_root", "rtgi_hip_depth",
+    "rtgi_hip_incoherent_ray_cost",
     "rtgi_hip_get_nodes", "rtgi_hip_get_triangle_order", "rtgi_hip_closest_hit", "rtgi_hip_any_hit",
     "rtgi_hip_closest_hit_device", "rtgi_hip_any_hit_device", "rtgi_hip_camera_rays_device",
     "rtgi_hip_shadow_rays_device", "rtgi_hip_bounce_rays_device", "rtgi_hip_profile_begin", "rtgi_hip_profile_end",
@@ -62,6 +63,8 @@ def lib():
             f = getattr(L, "rtgi_hip_" + name)
             f.argtypes = [vp]
             f.restype = u32
+        L.rtgi_hip_incoherent_ray_cost.argtypes = [vp]
+        L.rtgi_hip_incoherent_ray_cost.restype = C.c_float
         L.rtgi_hip_get_nodes.argtypes = [vp, vp]
         L.rtgi_hip_get_triangle_order.argtypes = [vp, vp]
         L.rtgi_hip_closest_hit.argtypes = [vp, vp, u32, vp]
@@ -148,6 +151,11 @@ class HipBvhTracer:
     @property
     def depth(self):
         return lib().rtgi_hip_depth(self._h)
+
+    @property
+    def incoherent_ray_cost(self):
+        """Mean inner-node pops of the probe rays traced at build: what "hip reorder auto" decides by."""
+        return lib().rtgi_hip_incoherent_ray_cost(self._h)
 
     def nodes(self):
         out = np.zeros(lib().rtgi_hip_num_nodes(self._h), NODE56_DTYPE)

@@ -202,7 +202,8 @@ def test_batch_sizes_and_argument_checks():
 
 def test_large_batches_are_reordered_without_changing_results():
     # batches of 2^16 rays and more are sorted (direction octant, length class, Morton code of the origin) before
-    # tracing and each XCD starts on its own part; hits, any-hit bytes and per-ray counts must not notice
+    # tracing when their origins are scattered ("auto"), always ("on") or never ("off"), and each XCD starts on
+    # its own part; hits, any-hit bytes and per-ray counts must not notice
     import torch
     for scene, cmds in ((scenes.soup(20000, seed=8, size=0.2), ()), (scenes.skewed(30000, seed=6), ("sm",))):
         pos, tri, _ = scene
@@ -213,12 +214,23 @@ def test_large_batches_are_reordered_without_changing_results():
         rays = _mixed_rays(pos, 300000, seed=21)
         want, want_counts = o.closest_hit(rays, counts=True)
         want_any, want_any_counts = o.any_hit(rays, counts=True)
-        assert_hits_equal(t.closest_hit(rays), want, "reordered closest_hit")
+        assert_hits_equal(t.closest_hit(rays), want, "closest_hit, reorder auto")
         assert t.interprete("hip", "reorder off")
         assert_hits_equal(t.closest_hit(rays), want, "closest_hit in given order")
-        assert t.interprete("hip", "reorder on")
-        assert (t.any_hit(rays) == want_any).all()
-        _check_device_path(t, rays, want, want_counts, want_any, want_any_counts)
+        # coherent rays (one origin, neighbouring directions): "auto" keeps their order, "on" sorts them anyway
+        coherent = rays.copy()
+        coherent[:, 0:3] = pos.mean(0)
+        coherent = coherent[np.lexsort((coherent[:, 5], coherent[:, 4], coherent[:, 3]))]
+        want_coherent = o.closest_hit(coherent)
+        for mode in ("auto", "on"):
+            assert t.interprete("hip", "reorder " + mode)
+            assert_hits_equal(t.closest_hit(coherent), want_coherent, "coherent rays, reorder " + mode)
+            assert (t.any_hit(rays) == want_any).all()
+            _check_device_path(t, rays, want, want_counts, want_any, want_any_counts)
+        with pytest.raises(tracer.RtgiHipError):
+            t.interprete("hip", "reorder sometimes")
+        # the figure "auto" decides by: mean inner-node pops of probe rays, same order of magnitude as these rays'
+        assert 0.2 * want_counts[:, 0].mean() < t.incoherent_ray_cost < 5.0 * want_counts[:, 0].mean()
 
 
 def test_upload_of_a_foreign_tree():
