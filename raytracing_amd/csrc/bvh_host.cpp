@@ -383,14 +383,29 @@ bool validate_tree(HostTree &t, uint32_t n_triangles, std::string &err) {
 void flatten_tree(const HostTree &t, const SceneView &scene, int layout, FlatTree &out) {
 	const uint32_t n = (uint32_t)t.nodes.size();
 	// Inner nodes are renumbered level by level (breadth first): the upper levels, which every ray visits,
-	// become one contiguous block (fully used cache lines, resident in every L2), and the two children of
-	// a node land in the same 128-byte line. RTGI_HIP_NODE_ORDER=dfs keeps the reference's pre-order.
+	// become one contiguous block (the kernel keeps the first ones in LDS), and two inner siblings share one
+	// aligned 128-byte line, so that fetching the nearer child brings in the one that waits on the stack.
+	// RTGI_HIP_NODE_ORDER=dfs keeps the reference's pre-order, =bfs numbers without the alignment gaps.
 	std::vector<int32_t> inner_id(n, -1);
 	uint32_t n_inner = 0;
 	const char *order_env = getenv("RTGI_HIP_NODE_ORDER");
 	if (order_env && std::string(order_env) == "dfs") {
 		for (uint32_t i = 0; i < n; ++i)
 			if (t.nodes[i].link_r >= 0) inner_id[i] = (int32_t)n_inner++;
+	} else if (!(order_env && std::string(order_env) == "bfs")) {
+		std::vector<uint32_t> queue;
+		queue.reserve(n);
+		if (t.nodes[t.root].link_r >= 0) {
+			queue.push_back(t.root);
+			inner_id[t.root] = (int32_t)n_inner++;
+		}
+		for (size_t head = 0; head < queue.size(); ++head) {
+			const rtgi_node56 &nd = t.nodes[queue[head]];
+			const bool li = t.nodes[nd.link_l].link_r >= 0, ri = t.nodes[nd.link_r].link_r >= 0;
+			if (li && ri && (n_inner & 1u)) ++n_inner;
+			if (li) inner_id[nd.link_l] = (int32_t)n_inner++, queue.push_back((uint32_t)nd.link_l);
+			if (ri) inner_id[nd.link_r] = (int32_t)n_inner++, queue.push_back((uint32_t)nd.link_r);
+		}
 	} else {
 		std::vector<uint32_t> queue;
 		queue.reserve(n);

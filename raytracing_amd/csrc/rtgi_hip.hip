@@ -66,6 +66,7 @@ struct rtgi_hip_tracer {
 	std::vector<rtgi_ray> probe_rays;
 	uint32_t node_bytes = 0, tri_bytes = 0;
 	int refill_min = 16, leaf_min = 8;
+	bool top_in_lds = true;
 	uint32_t n_segments = 8;
 	int32_t *d_spill = nullptr;
 	uint32_t *d_counter = nullptr;
@@ -129,6 +130,7 @@ int upload(rtgi_hip_tracer *h, const rtgi::SceneView &scene) {
 	h->tri_bytes = (uint32_t)tri_bytes;
 	if (const char *e = getenv("RTGI_HIP_REFILL_MIN")) h->refill_min = std::max(1, std::min(64, atoi(e)));
 	if (const char *e = getenv("RTGI_HIP_SEGMENTS")) h->n_segments = atoi(e) == 1 ? 1u : 8u;
+	if (const char *e = getenv("RTGI_HIP_TOP_IN_LDS")) h->top_in_lds = atoi(e) != 0;
 	if (const char *e = getenv("RTGI_HIP_LEAF_MIN")) h->leaf_min = std::max(1, std::min(64, atoi(e)));
 	if (!flat.nodes.empty()) HIP_TRY(h, hipMemcpy(h->d_nodes, flat.nodes.data(), flat.nodes.size() * sizeof(float), hipMemcpyHostToDevice));
 	HIP_TRY(h, hipMemcpy(h->d_tris, flat.tris.data(), flat.tris.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -295,6 +297,7 @@ int launch(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint32_t n, void *d_out, 
 #endif
 	a.refill_min = h->refill_min;
 	a.leaf_min = h->leaf_min;
+	a.top_nodes = h->top_in_lds ? rtgi_dev::TOP_NODES : 0;
 	uint32_t blocks = (n + BLOCK - 1) / BLOCK;
 	if (blocks > h->grid_blocks) blocks = h->grid_blocks;
 	a.spill_stride = blocks * BLOCK;

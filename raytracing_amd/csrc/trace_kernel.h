@@ -31,6 +31,10 @@ namespace rtgi_dev {
 constexpr int BLOCK = 256;      // 4 waves per workgroup
 constexpr int STACK_LDS = 24;   // pending nodes per lane held in LDS (beyond the one in a register)
 constexpr int COUNTER_STRIDE = 32;
+#ifndef RTGI_TOP_NODES
+#define RTGI_TOP_NODES 256
+#endif
+constexpr int TOP_NODES = RTGI_TOP_NODES;  // inner nodes 0..TOP_NODES-1 (the top of the breadth-first numbering) are kept in LDS
 constexpr int32_t IDLE = INT32_MIN;  // lane has no ray; leaf references are ~slot with slot < 2^30
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -54,6 +58,7 @@ struct TraceArgs {
 	int32_t root_ref;
 	int32_t refill_min;     // refill a wave once this many lanes are idle
 	int32_t leaf_min;       // leave the inner-node loop once this many lanes have left it
+	int32_t top_nodes;      // 0, or TOP_NODES: visits to the first nodes are served from a copy in LDS
 #ifdef RTGI_DIAG
 	unsigned long long *diag;  // diagnostic build only: 8 counters summed over all waves
 #endif
@@ -93,6 +98,7 @@ __device__ __forceinline__ float next_up(float x) {
 template <bool ANY, bool COUNT, bool DEEP>
 __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 	__shared__ int32_t s_stack[STACK_LDS][BLOCK];
+	__shared__ u32x4 s_top[4][TOP_NODES];  // [quad][node]: lanes on different nodes read different 16-byte slots
 	const int tid = threadIdx.x;
 	const int lane = tid & 63;
 	const uint32_t gl = blockIdx.x * BLOCK + tid;
@@ -100,6 +106,15 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 	const uint32_t n_rays = a.n_rays;
 	const __amdgpu_buffer_rsrc_t node_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.nodes), 0, (int)a.node_bytes, 0x00020000);
 	const __amdgpu_buffer_rsrc_t tri_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.tris), 0, (int)a.tri_bytes, 0x00020000);
+
+	// Every ray walks the top of the tree; a copy in LDS takes those visits off the vector cache, whose access
+	// rate is what the kernel runs against. (Reads beyond the node array return zeros.)
+	const int32_t top_nodes = a.top_nodes;
+	if (top_nodes) {
+		for (int i = tid; i < 4 * TOP_NODES; i += BLOCK)
+			s_top[i & 3][i >> 2] = __builtin_amdgcn_raw_buffer_load_b128(node_rsrc, i << 4, 0, 0);
+		__syncthreads();
+	}
 
 	float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, ix = 0, iy = 0, iz = 0, t_min = 0, t_max = 0;
 	float lim = 0;       // plain rays: entry distances below this pass "t1 <= t_max (&& t1 < closest t)"
@@ -229,10 +244,15 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 #endif
 				if (at_inner) {
 					const int voff = cur << 6;
-					const u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(node_rsrc, voff, 0, 0);
-					const u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(node_rsrc, voff + 16, 0, 0);
-					const u32x4 q2 = __builtin_amdgcn_raw_buffer_load_b128(node_rsrc, voff + 32, 0, 0);
-					const u32x4 q3 = __builtin_amdgcn_raw_buffer_load_b128(node_rsrc, voff + 48, 0, 0);
+					u32x4 q0, q1, q2, q3;
+					if (cur < top_nodes) {
+						q0 = s_top[0][cur], q1 = s_top[1][cur], q2 = s_top[2][cur], q3 = s_top[3][cur];
+					} else {
+						q0 = __builtin_amdgcn_raw_buffer_load_b128(node_rsrc, voff, 0, 0);
+						q1 = __builtin_amdgcn_raw_buffer_load_b128(node_rsrc, voff + 16, 0, 0);
+						q2 = __builtin_amdgcn_raw_buffer_load_b128(node_rsrc, voff + 32, 0, 0);
+						q3 = __builtin_amdgcn_raw_buffer_load_b128(node_rsrc, voff + 48, 0, 0);
+					}
 					if (COUNT) ++n_inner;
 					auto pair = [](uint32_t u, uint32_t v) { return f32x2{__uint_as_float(u), __uint_as_float(v)}; };
 					// .x = left child, .y = right child; (box - o) * id as in libgi/intersect.h:210-221
