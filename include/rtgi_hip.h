@@ -154,6 +154,36 @@ int rtgi_hip_camera_rays_device(rtgi_hip_tracer *h, const rtgi_camera *cam, cons
 int rtgi_hip_shadow_rays_device(rtgi_hip_tracer *h, const rtgi_hit *d_hits, uint32_t n, const float light_pos[3],
                                 rtgi_ray *d_shadow, void *stream);
 
+/* ---- shading and accumulation on the GPU: the callers after the tracer ---------------------------------- */
+
+/* The part of the scene the shading stages read, given once after build(): per-vertex normals (3 floats,
+ * `normal_stride` bytes apart: &scene.vertices[0].norm, 32), the triangles as passed to build() with the
+ * material index as fourth uint32 (libgi/rt.h:35-38, stride 16), and one albedo per material
+ * (material::albedo, libgi/material.h:54; textures are not supported). Stores, per triangle id as hits
+ * report it, the shading normal normalize(a.norm + b.norm + c.norm) of diff_geom (libgi/rt.cpp:10). */
+int rtgi_hip_set_shading(rtgi_hip_tracer *h, const void *vertex_normals, size_t normal_stride, uint32_t n_vertices,
+                         const void *triangles, size_t tri_stride, uint32_t n_triangles, const float *albedo_rgb,
+                         uint32_t n_materials);
+
+/* primary_hit_display::sample_pixel, gi/primary-hit.cpp:16-30, for a batch: d_radiance[i] = albedo of the
+ * triangle d_hits[i] names, black for a miss. d_radiance: n x float4 (rgb, 0). */
+int rtgi_hip_shade_primary_device(rtgi_hip_tracer *h, const rtgi_hit *d_hits, uint32_t n, float *d_radiance, void *stream);
+
+/* local_illumination::sample_pixel, gi/primary-hit.cpp:32-57, for a batch, a point light (pointlight,
+ * libgi/scene.h:58-63: power = 4 pi col) and the lambertian BRDF (libgi/material.cpp:17-20): d_occluded is
+ * any_hit's answer for the rays of rtgi_hip_shadow_rays_device on the same hits. */
+int rtgi_hip_shade_local_device(rtgi_hip_tracer *h, const rtgi_hit *d_hits, const uint8_t *d_occluded, uint32_t n,
+                                const float light_pos[3], const float light_col[3], float *d_radiance, void *stream);
+
+/* framebuffer::add, libgi/framebuffer.cpp:10-18, one sample for each of n pixels: d_framebuffer is n x float4
+ * (running mean rgb, sample count in w), zero-filled by the caller like framebuffer::clear. */
+int rtgi_hip_framebuffer_add_device(rtgi_hip_tracer *h, float *d_framebuffer, const float *d_radiance, uint32_t n, void *stream);
+
+/* framebuffer::png, libgi/framebuffer.cpp:21-30, without the file: 8-bit rgb, clamped, gamma 1/2.2, rows
+ * flipped. d_rgb: 3 * w * h bytes. */
+int rtgi_hip_framebuffer_rgb8_device(rtgi_hip_tracer *h, const float *d_framebuffer, uint32_t w, uint32_t height,
+                                     uint8_t *d_rgb, void *stream);
+
 /* One diffuse bounce (no counterpart in the reference, which has no path tracer): for every ray that hit
  * something, a ray from the hit point into a cosine-weighted direction about the geometric normal facing the
  * incoming ray, random numbers keyed by (ray index, bounce, seed). The new rays are written densely to d_out in

@@ -136,13 +136,19 @@ public:
 	void build(Scene *s) {
 		check(rtgi_hip_build(h, &s->vertices[0].pos, sizeof(s->vertices[0]), (uint32_t)s->vertices.size(), &s->triangles[0].a,
 		                     sizeof(s->triangles[0]), (uint32_t)s->triangles.size()));
-		if (!indexed) {
-			std::vector<uint32_t> order(rtgi_hip_num_index(h));
-			check(rtgi_hip_get_triangle_order(h, order.data()));
-			auto shuffled = s->triangles;
-			for (size_t i = 0; i < order.size(); ++i) shuffled[i] = s->triangles[order[i]];
-			s->triangles = std::move(shuffled);
-		}
+		permute(s);
+	}
+
+	// Hands the GPU shading stages (rtgi_hip_shade_*_device) their part of the scene: vertex normals, material
+	// ids and one albedo per material (3 floats each, material::albedo of libgi/material.h:54). Call between
+	// rtgi_hip_build and the permutation of scene->triangles, i.e. use build(s, albedo, n) below.
+	template <class Scene>
+	void build(Scene *s, const float *albedo_rgb, uint32_t n_materials) {
+		check(rtgi_hip_build(h, &s->vertices[0].pos, sizeof(s->vertices[0]), (uint32_t)s->vertices.size(), &s->triangles[0].a,
+		                     sizeof(s->triangles[0]), (uint32_t)s->triangles.size()));
+		check(rtgi_hip_set_shading(h, &s->vertices[0].norm, sizeof(s->vertices[0]), (uint32_t)s->vertices.size(), &s->triangles[0].a,
+		                           sizeof(s->triangles[0]), (uint32_t)s->triangles.size(), albedo_rgb, n_materials));
+		permute(s);
 	}
 
 	// interprete(command, in), bvh2.cpp:503-555. Errors are printed like the renderer's error() macro does
@@ -173,6 +179,15 @@ public:
 	rtgi_hip_tracer *handle() { return h; }
 
 private:
+	template <class Scene>
+	void permute(Scene *s) {
+		if (indexed) return;
+		std::vector<uint32_t> order(rtgi_hip_num_index(h));
+		check(rtgi_hip_get_triangle_order(h, order.data()));
+		auto shuffled = s->triangles;
+		for (size_t i = 0; i < order.size(); ++i) shuffled[i] = s->triangles[order[i]];
+		s->triangles = std::move(shuffled);
+	}
 	void check(int rc) {
 		if (rc < 0) throw std::runtime_error(std::string("rtgi_hip: ") + rtgi_hip_last_error(h));
 	}

@@ -44,6 +44,9 @@ struct rtgi_hip_tracer {
 	void *d_nodes = nullptr;
 	void *d_tris = nullptr;
 	float4 *d_corners = nullptr;  // triangle corners by reported id
+	float4 *d_normals = nullptr;  // shading normal and material index by reported id (set_shading)
+	float4 *d_albedo = nullptr;
+	uint32_t n_materials = 0, n_scene_triangles = 0, n_scene_vertices = 0;
 	uint32_t *d_wave_counts = nullptr;
 	size_t wave_counts_cap = 0;
 
@@ -97,7 +100,10 @@ void free_device_tree(rtgi_hip_tracer *h) {
 	if (h->d_tris) (void)hipFree(h->d_tris);
 	if (h->d_spill) (void)hipFree(h->d_spill);
 	if (h->d_corners) (void)hipFree(h->d_corners);
-	h->d_corners = nullptr;
+	if (h->d_normals) (void)hipFree(h->d_normals);
+	if (h->d_albedo) (void)hipFree(h->d_albedo);
+	h->d_corners = h->d_normals = h->d_albedo = nullptr;
+	h->n_materials = 0;
 	h->d_nodes = h->d_tris = nullptr;
 	h->d_spill = nullptr;
 	h->built = false;
@@ -153,6 +159,8 @@ int upload(rtgi_hip_tracer *h, const rtgi::SceneView &scene) {
 	}
 	if (const char *e = getenv("RTGI_HIP_REORDER")) h->reorder = std::max(0, std::min(2, atoi(e)));
 	h->root_ref = flat.root_ref;
+	h->n_scene_triangles = scene.n_triangles;
+	h->n_scene_vertices = scene.n_vertices;
 	h->built = true;
 	// probe rays for the reorder policy: from random points of random triangles into random directions
 	h->probe_rays.clear();
@@ -656,6 +664,127 @@ int rtgi_hip_shadow_rays_device(rtgi_hip_tracer *h, const rtgi_hit *d_hits, uint
 	for (int k = 0; k < 3; ++k) a.light[k] = light_pos[k];
 	a.n = n;
 	hipLaunchKernelGGL(rtgi_dev::shadow_rays_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+	HIP_TRY(h, hipGetLastError());
+	return RTGI_OK;
+}
+
+int rtgi_hip_set_shading(rtgi_hip_tracer *h, const void *vertex_normals, size_t normal_stride, uint32_t n_vertices,
+                         const void *triangles, size_t tri_stride, uint32_t n_triangles, const float *albedo_rgb,
+                         uint32_t n_materials) {
+	if (!h) return RTGI_ERR_INVALID;
+	if (h->device < 0) return fail(h, RTGI_ERR_DEVICE, "host-only handle: needs a GPU");
+	if (!h->built) return fail(h, RTGI_ERR_NOT_BUILT, "no acceleration structure: call build first");
+	if (!vertex_normals || !triangles || !albedo_rgb || n_materials == 0 || normal_stride < 12 || tri_stride < 16)
+		return fail(h, RTGI_ERR_INVALID, "set_shading: null array, no materials, or strides below 12 / 16 bytes");
+	if (n_triangles != h->n_scene_triangles || n_vertices != h->n_scene_vertices)
+		return fail(h, RTGI_ERR_INVALID, "set_shading: not the scene that was built");
+	const bool flat = h->cfg.layout == RTGI_LAYOUT_FLAT;
+	const uint32_t n_ids = flat ? (uint32_t)h->tree.order.size() : n_triangles;
+	std::vector<float> normals((size_t)n_ids * 4);
+	for (uint32_t id = 0; id < n_ids; ++id) {
+		const uint32_t src = flat ? h->tree.order[id] : id;  // hits of the flat layout name slots of the permuted list
+		uint32_t t[4];
+		memcpy(t, (const unsigned char *)triangles + (size_t)src * tri_stride, 16);
+		if (t[0] >= n_vertices || t[1] >= n_vertices || t[2] >= n_vertices)
+			return fail(h, RTGI_ERR_INVALID, "set_shading: vertex id out of range");
+		if (t[3] >= n_materials) return fail(h, RTGI_ERR_INVALID, "set_shading: material id out of range");
+		float na[3], nb[3], nc[3], sum[3];
+		memcpy(na, (const unsigned char *)vertex_normals + (size_t)t[0] * normal_stride, 12);
+		memcpy(nb, (const unsigned char *)vertex_normals + (size_t)t[1] * normal_stride, 12);
+		memcpy(nc, (const unsigned char *)vertex_normals + (size_t)t[2] * normal_stride, 12);
+		for (int k = 0; k < 3; ++k) sum[k] = na[k] + nb[k] + nc[k];
+		// glm::normalize: v * inversesqrt(dot(v, v))
+		const float px = sum[0] * sum[0], py = sum[1] * sum[1], pz = sum[2] * sum[2];
+		const float inv = 1.0f / std::sqrt(px + py + pz);
+		float *o = &normals[(size_t)id * 4];
+		for (int k = 0; k < 3; ++k) o[k] = sum[k] * inv;
+		memcpy(o + 3, &t[3], 4);
+	}
+	std::vector<float> albedo((size_t)n_materials * 4, 0.0f);
+	for (uint32_t m = 0; m < n_materials; ++m)
+		for (int k = 0; k < 3; ++k) albedo[(size_t)m * 4 + k] = albedo_rgb[(size_t)m * 3 + k];
+	HIP_TRY(h, hipSetDevice(h->device));
+	if (h->d_normals) (void)hipFree(h->d_normals);
+	if (h->d_albedo) (void)hipFree(h->d_albedo);
+	h->d_normals = h->d_albedo = nullptr;
+	h->n_materials = 0;
+	HIP_TRY(h, hipMalloc((void **)&h->d_normals, std::max<size_t>(normals.size() * sizeof(float), 16)));
+	HIP_TRY(h, hipMalloc((void **)&h->d_albedo, albedo.size() * sizeof(float)));
+	if (!normals.empty()) HIP_TRY(h, hipMemcpy(h->d_normals, normals.data(), normals.size() * sizeof(float), hipMemcpyHostToDevice));
+	HIP_TRY(h, hipMemcpy(h->d_albedo, albedo.data(), albedo.size() * sizeof(float), hipMemcpyHostToDevice));
+	h->n_materials = n_materials;
+	return RTGI_OK;
+}
+
+namespace {
+int shade(rtgi_hip_tracer *h, bool local, const rtgi_hit *d_hits, const uint8_t *d_occluded, uint32_t n, const float *light_pos,
+          const float *light_col, float *d_radiance, void *stream) {
+	if (!h) return RTGI_ERR_INVALID;
+	if (h->device < 0) return fail(h, RTGI_ERR_DEVICE, "host-only handle: needs a GPU");
+	if (!h->built) return fail(h, RTGI_ERR_NOT_BUILT, "no acceleration structure: call build first");
+	if (!h->n_materials) return fail(h, RTGI_ERR_NOT_BUILT, "no shading data: call set_shading after build");
+	if (n == 0) return RTGI_OK;
+	if (!d_hits || !d_radiance || ((reinterpret_cast<uintptr_t>(d_hits) | reinterpret_cast<uintptr_t>(d_radiance)) & 15u))
+		return fail(h, RTGI_ERR_INVALID, "shade: null or misaligned buffer");
+	if (local && (!d_occluded || !light_pos || !light_col)) return fail(h, RTGI_ERR_INVALID, "shade_local: null argument");
+	HIP_TRY(h, hipSetDevice(h->device));
+	rtgi_dev::ShadeArgs a;
+	a.hits = (const float4 *)d_hits;
+	a.occluded = d_occluded;
+	a.corners = h->d_corners;
+	a.normals = h->d_normals;
+	a.albedo = h->d_albedo;
+	a.out = (float4 *)d_radiance;
+	const float pi = (float)3.14159265358979323846;  // libgi/rt.h:14
+	for (int k = 0; k < 3; ++k) {
+		a.light[k] = local ? light_pos[k] : 0.0f;
+		a.power[k] = local ? 4 * pi * light_col[k] : 0.0f;  // pointlight::power, libgi/scene.cpp:216-218
+	}
+	a.n = n;
+	a.n_materials = h->n_materials;
+	if (local)
+		hipLaunchKernelGGL(rtgi_dev::shade_local_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+	else
+		hipLaunchKernelGGL(rtgi_dev::shade_primary_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+	HIP_TRY(h, hipGetLastError());
+	return RTGI_OK;
+}
+}  // namespace
+
+int rtgi_hip_shade_primary_device(rtgi_hip_tracer *h, const rtgi_hit *d_hits, uint32_t n, float *d_radiance, void *stream) {
+	return shade(h, false, d_hits, nullptr, n, nullptr, nullptr, d_radiance, stream);
+}
+
+int rtgi_hip_shade_local_device(rtgi_hip_tracer *h, const rtgi_hit *d_hits, const uint8_t *d_occluded, uint32_t n,
+                                const float light_pos[3], const float light_col[3], float *d_radiance, void *stream) {
+	return shade(h, true, d_hits, d_occluded, n, light_pos, light_col, d_radiance, stream);
+}
+
+int rtgi_hip_framebuffer_add_device(rtgi_hip_tracer *h, float *d_framebuffer, const float *d_radiance, uint32_t n, void *stream) {
+	if (!h) return RTGI_ERR_INVALID;
+	if (h->device < 0) return fail(h, RTGI_ERR_DEVICE, "host-only handle: needs a GPU");
+	if (n == 0) return RTGI_OK;
+	if (!d_framebuffer || !d_radiance ||
+	    ((reinterpret_cast<uintptr_t>(d_framebuffer) | reinterpret_cast<uintptr_t>(d_radiance)) & 15u))
+		return fail(h, RTGI_ERR_INVALID, "framebuffer_add: null or misaligned buffer");
+	HIP_TRY(h, hipSetDevice(h->device));
+	hipLaunchKernelGGL(rtgi_dev::framebuffer_add_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+	                   (float4 *)d_framebuffer, (const float4 *)d_radiance, n);
+	HIP_TRY(h, hipGetLastError());
+	return RTGI_OK;
+}
+
+int rtgi_hip_framebuffer_rgb8_device(rtgi_hip_tracer *h, const float *d_framebuffer, uint32_t w, uint32_t height,
+                                     uint8_t *d_rgb, void *stream) {
+	if (!h) return RTGI_ERR_INVALID;
+	if (h->device < 0) return fail(h, RTGI_ERR_DEVICE, "host-only handle: needs a GPU");
+	if (w == 0 || height == 0) return RTGI_OK;
+	if ((uint64_t)w * height > 0x7fffffffull) return fail(h, RTGI_ERR_INVALID, "framebuffer_rgb8: image too large");
+	if (!d_framebuffer || !d_rgb || (reinterpret_cast<uintptr_t>(d_framebuffer) & 15u))
+		return fail(h, RTGI_ERR_INVALID, "framebuffer_rgb8: null or misaligned buffer");
+	HIP_TRY(h, hipSetDevice(h->device));
+	hipLaunchKernelGGL(rtgi_dev::framebuffer_rgb8_kernel, dim3((w * height + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+	                   (const float4 *)d_framebuffer, w, height, d_rgb);
 	HIP_TRY(h, hipGetLastError());
 	return RTGI_OK;
 }

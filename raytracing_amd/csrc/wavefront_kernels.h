@@ -189,4 +189,92 @@ __global__ __launch_bounds__(256) void bounce_write_kernel(BounceArgs a) {
 	if (a.parent) a.parent[slot] = i;
 }
 
+// ---- shading and accumulation: what the renderer's algorithms do with a hit ---------------------------------
+
+struct ShadeArgs {
+	const float4 *hits;
+	const uint8_t *occluded;  // local illumination: any_hit result of the shadow rays
+	const float4 *corners;    // 3 x float4 per reported triangle id
+	const float4 *normals;    // per reported triangle id: shading normal xyz, material index (bits) in w
+	const float4 *albedo;     // per material
+	float4 *out;              // radiance rgb, w = 0
+	float light[3], power[3];
+	uint32_t n, n_materials;
+};
+
+__device__ __forceinline__ float4 material_albedo(const ShadeArgs &a, float4 normal) {
+	const uint32_t m = __float_as_uint(normal.w);
+	return m < a.n_materials ? a.albedo[m] : make_float4(0, 0, 0, 0);
+}
+
+// primary_hit_display::sample_pixel, gi/primary-hit.cpp:16-30: the albedo of what the ray hit, else black
+// (diff_geom::albedo without a texture, libgi/rt.cpp:30-34)
+__global__ __launch_bounds__(256) void shade_primary_kernel(ShadeArgs a) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= a.n) return;
+	const float4 hit = a.hits[i];
+	float4 c = make_float4(0, 0, 0, 0);
+	if (hit.x != FLT_MAX) {
+		c = material_albedo(a, a.normals[__float_as_uint(hit.w)]);
+		c.w = 0.0f;
+	}
+	a.out[i] = c;
+}
+
+// local_illumination::sample_pixel, gi/primary-hit.cpp:32-57, for a point light and the lambertian BRDF
+// (libgi/material.cpp:17-20): power * f / d^2 where the shadow ray found nothing, with power = 4 pi col
+// (libgi/scene.cpp:216-218) and f = albedo / pi on the side of the shading normal that faces the light.
+__global__ __launch_bounds__(256) void shade_local_kernel(ShadeArgs a) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= a.n) return;
+	const float4 hit = a.hits[i];
+	float4 c = make_float4(0, 0, 0, 0);
+	if (hit.x != FLT_MAX && !a.occluded[i]) {
+		float x, y, z;
+		float4 A, B, C;
+		hit_point(a.corners, hit, x, y, z, A, B, C);
+		const float4 ns = a.normals[__float_as_uint(hit.w)];
+		const float lx = a.light[0] - x, ly = a.light[1] - y, lz = a.light[2] - z;
+		const float px = lx * lx, py = ly * ly, pz = lz * lz;
+		const float d = sqrtf(px + py + pz);
+		const float inv = 1.0f / d;
+		const float wx = lx * inv, wy = ly * inv, wz = lz * inv;
+		const float qx = ns.x * wx, qy = ns.y * wy, qz = ns.z * wz;
+		if (qx + qy + qz > 0.0f) {  // same_hemisphere(w_i, ns), libgi/util.h:115-117
+			const float one_over_pi = (float)(1.0 / 3.14159265358979323846);  // libgi/rt.h:15
+			const float4 alb = material_albedo(a, ns);
+			const float dd = d * d;
+			c.x = a.power[0] * (one_over_pi * alb.x) / dd;
+			c.y = a.power[1] * (one_over_pi * alb.y) / dd;
+			c.z = a.power[2] * (one_over_pi * alb.z) / dd;
+		}
+	}
+	a.out[i] = c;
+}
+
+// framebuffer::add, libgi/framebuffer.cpp:10-18, with one sample per pixel: rgb is the running mean, w the
+// number of samples so far.
+__global__ __launch_bounds__(256) void framebuffer_add_kernel(float4 *fb, const float4 *radiance, uint32_t n) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	const float4 c = fb[i], r = radiance[i];
+	const float new_count = c.w + 1.0f;
+	fb[i] = make_float4((c.x * c.w + r.x) / new_count, (c.y * c.w + r.y) / new_count, (c.z * c.w + r.z) / new_count, new_count);
+}
+
+// framebuffer::png, libgi/framebuffer.cpp:21-30: clamp to [0,1], gamma 1/2.2, scale to 255, truncate to a
+// byte, first image row = last framebuffer row.
+__global__ __launch_bounds__(256) void framebuffer_rgb8_kernel(const float4 *fb, uint32_t w, uint32_t h, uint8_t *rgb) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= w * h) return;
+	const uint32_t x = i % w, y = i / w;
+	const float4 c = fb[i];
+	auto tone = [](float v) {
+		v = fminf(fmaxf(v, 0.0f), 1.0f);
+		return (uint8_t)(powf(v, 1.0f / 2.2f) * 255.0f);
+	};
+	uint8_t *o = rgb + 3 * ((size_t)(h - 1u - y) * w + x);
+	o[0] = tone(c.x), o[1] = tone(c.y), o[2] = tone(c.z);
+}
+
 }  // namespace rtgi_dev

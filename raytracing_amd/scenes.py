@@ -6,6 +6,8 @@ class and size.  Every generator returns ``(pos, tri, nrm)``: float32 vertex pos
 vertex ids per triangle (nt, 3) and float32 vertex normals (nv, 3).  Like assimp without vertex joining,
 every triangle owns three vertices of its own.
 """
+import os
+
 import numpy as np
 
 
@@ -43,6 +45,64 @@ def load_obj(path):
     v = np.asarray(verts, dtype=np.float32)
     fa = np.asarray(faces, dtype=np.int64)
     return _finish(v[fa])
+
+
+def load_obj_materials(path):
+    """OBJ reader that keeps what shading needs: positions, normals ('vn', zero if a corner has none), the material
+    of every triangle ('usemtl') and, from the 'mtllib' beside the file if present, Kd / Ks per material.
+    Returns dict(pos (3 nt, 3), tri (nt, 3), normals (3 nt, 3), material_id (nt,), materials [names], kd, ks)."""
+    verts, vnorms, faces, fnorms, fmat, names = [], [], [], [], [], []
+    mtl_file = None
+    current = 0
+    with open(path) as f:
+        for line in f:
+            p = line.split()
+            if not p:
+                continue
+            if p[0] == "v":
+                verts.append([float(x) for x in p[1:4]])
+            elif p[0] == "vn":
+                vnorms.append([float(x) for x in p[1:4]])
+            elif p[0] == "mtllib":
+                mtl_file = os.path.join(os.path.dirname(path), p[1])
+            elif p[0] == "usemtl":
+                if p[1] not in names:
+                    names.append(p[1])
+                current = names.index(p[1])
+            elif p[0] == "f":
+                corners = []
+                for tok in p[1:]:
+                    parts = tok.split("/")
+                    vi = int(parts[0])
+                    ni = int(parts[2]) if len(parts) > 2 and parts[2] else 0
+                    corners.append((vi - 1 if vi > 0 else len(verts) + vi, ni - 1 if ni > 0 else (len(vnorms) + ni if ni else -1)))
+                for k in range(1, len(corners) - 1):
+                    faces.append([corners[0][0], corners[k][0], corners[k + 1][0]])
+                    fnorms.append([corners[0][1], corners[k][1], corners[k + 1][1]])
+                    fmat.append(current)
+    if not names:
+        names = ["default"]
+    v = np.asarray(verts, np.float32)
+    vn = np.vstack([np.asarray(vnorms, np.float32).reshape(-1, 3), np.zeros((1, 3), np.float32)])  # index -1 -> zero
+    pos = v[np.asarray(faces, np.int64)].reshape(-1, 3)
+    normals = vn[np.asarray(fnorms, np.int64)].reshape(-1, 3)
+    tri = np.arange(len(pos), dtype=np.uint32).reshape(-1, 3)
+    kd, ks = np.zeros((len(names), 3), np.float32), np.zeros((len(names), 3), np.float32)
+    if mtl_file and os.path.exists(mtl_file):
+        cur = None
+        with open(mtl_file) as f:
+            for line in f:
+                p = line.split()
+                if not p:
+                    continue
+                if p[0] == "newmtl":
+                    cur = names.index(p[1]) if p[1] in names else None
+                elif cur is not None and p[0] == "Kd":
+                    kd[cur] = [float(x) for x in p[1:4]]
+                elif cur is not None and p[0] == "Ks":
+                    ks[cur] = [float(x) for x in p[1:4]]
+    return dict(pos=np.ascontiguousarray(pos), tri=tri, normals=np.ascontiguousarray(normals),
+                material_id=np.asarray(fmat, np.uint32), materials=names, kd=kd, ks=ks)
 
 
 def soup(n_tris=1 << 20, seed=1, extent=10.0, size=0.05):

@@ -27,7 +27,9 @@ EXPORTS = [
     "rtgi_hip_incoherent_ray_cost",
     "rtgi_hip_get_nodes", "rtgi_hip_get_triangle_order", "rtgi_hip_closest_hit", "rtgi_hip_any_hit",
     "rtgi_hip_closest_hit_device", "rtgi_hip_any_hit_device", "rtgi_hip_camera_rays_device",
-    "rtgi_hip_shadow_rays_device", "rtgi_hip_bounce_rays_device", "rtgi_hip_profile_begin", "rtgi_hip_profile_end",
+    "rtgi_hip_shadow_rays_device", "rtgi_hip_bounce_rays_device", "rtgi_hip_set_shading",
+    "rtgi_hip_shade_primary_device", "rtgi_hip_shade_local_device", "rtgi_hip_framebuffer_add_device",
+    "rtgi_hip_framebuffer_rgb8_device", "rtgi_hip_profile_begin", "rtgi_hip_profile_end",
     "rtgi_hip_last_error",
 ]
 
@@ -74,6 +76,11 @@ def lib():
         L.rtgi_hip_camera_rays_device.argtypes = [vp, vp, vp, vp, vp]
         L.rtgi_hip_shadow_rays_device.argtypes = [vp, vp, u32, vp, vp, vp]
         L.rtgi_hip_bounce_rays_device.argtypes = [vp, vp, vp, u32, u32, u32, vp, vp, vp, vp]
+        L.rtgi_hip_set_shading.argtypes = [vp, vp, sz, u32, vp, sz, u32, vp, u32]
+        L.rtgi_hip_shade_primary_device.argtypes = [vp, vp, u32, vp, vp]
+        L.rtgi_hip_shade_local_device.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp]
+        L.rtgi_hip_framebuffer_add_device.argtypes = [vp, vp, vp, u32, vp]
+        L.rtgi_hip_framebuffer_rgb8_device.argtypes = [vp, vp, u32, u32, vp, vp]
         L.rtgi_hip_profile_begin.argtypes = [vp]
         L.rtgi_hip_profile_end.argtypes = [vp, vp, vp]
         L.rtgi_hip_last_error.argtypes = [vp]
@@ -235,6 +242,48 @@ class HipBvhTracer:
             d_parent.data_ptr() if want_parent else None, d_count.data_ptr(), self._stream(stream)))
         m = int(d_count.item())
         return d_out[:m], (d_parent[:m] if want_parent else None)
+
+    # -- shading and accumulation on the device (the callers after the tracer) ----------------------------------
+    def set_shading(self, normals, tri, material_id, albedo):
+        """normals: (nv, 3) per-vertex normals; tri: the (nt, 3) triangles given to build(); material_id: (nt,);
+        albedo: (n_materials, 3). Must be repeated after every build()."""
+        normals = np.ascontiguousarray(normals, dtype=np.float32)
+        tri4 = np.empty((len(tri), 4), np.uint32)
+        tri4[:, 0:3] = tri
+        tri4[:, 3] = material_id
+        albedo = np.ascontiguousarray(albedo, dtype=np.float32)
+        self._check(lib().rtgi_hip_set_shading(self._h, normals.ctypes.data, 12, len(normals), tri4.ctypes.data, 16, len(tri4),
+                                               albedo.ctypes.data, len(albedo)))
+
+    def shade_primary_device(self, d_hits, stream=None):
+        """Albedo of what each hit names (primary_hit_display, gi/primary-hit.cpp:16-30) -> float32 (n, 4)."""
+        import torch
+        d_out = torch.empty((d_hits.shape[0], 4), dtype=torch.float32, device=d_hits.device)
+        self._check(lib().rtgi_hip_shade_primary_device(self._h, d_hits.data_ptr(), d_hits.shape[0], d_out.data_ptr(),
+                                                        self._stream(stream)))
+        return d_out
+
+    def shade_local_device(self, d_hits, d_occluded, light_pos, light_col, stream=None):
+        """Point light, lambertian BRDF, shadowed where d_occluded says so (local_illumination, :32-57)."""
+        import torch
+        d_out = torch.empty((d_hits.shape[0], 4), dtype=torch.float32, device=d_hits.device)
+        self._check(lib().rtgi_hip_shade_local_device(self._h, d_hits.data_ptr(), d_occluded.data_ptr(), d_hits.shape[0],
+                                                      (C.c_float * 3)(*light_pos), (C.c_float * 3)(*light_col),
+                                                      d_out.data_ptr(), self._stream(stream)))
+        return d_out
+
+    def framebuffer_add_device(self, d_framebuffer, d_radiance, stream=None):
+        """framebuffer::add (libgi/framebuffer.cpp:10-18), one sample per pixel, in place."""
+        self._check(lib().rtgi_hip_framebuffer_add_device(self._h, d_framebuffer.data_ptr(), d_radiance.data_ptr(),
+                                                          d_radiance.shape[0], self._stream(stream)))
+
+    def framebuffer_rgb8_device(self, d_framebuffer, w, h, stream=None):
+        """framebuffer::png without the file (libgi/framebuffer.cpp:21-30) -> uint8 (h, w, 3), top row first."""
+        import torch
+        d_rgb = torch.empty((h, w, 3), dtype=torch.uint8, device=d_framebuffer.device)
+        self._check(lib().rtgi_hip_framebuffer_rgb8_device(self._h, d_framebuffer.data_ptr(), w, h, d_rgb.data_ptr(),
+                                                           self._stream(stream)))
+        return d_rgb
 
     def profile_begin(self):
         self._check(lib().rtgi_hip_profile_begin(self._h))

@@ -119,3 +119,64 @@ def bounce_rays(pos, tri, rays, hits, seed=0, bounce=1, ray_index=None):
     out[:, 6] = EPS
     out[:, 7] = FLT_MAX
     return out, valid
+
+
+PI = np.float32(np.pi)                # libgi/rt.h:14
+ONE_OVER_PI = np.float32(1.0 / np.pi)  # libgi/rt.h:15
+
+
+def shading_normals(normals, tri):
+    """diff_geom::ns of libgi/rt.cpp:10: normalize(a.norm + b.norm + c.norm) per triangle, float32."""
+    f = np.float32
+    n = np.asarray(normals, f)[tri]
+    s = ((n[:, 0] + n[:, 1]) + n[:, 2]).astype(f)
+    sq = (s[:, 0] * s[:, 0] + s[:, 1] * s[:, 1]) + s[:, 2] * s[:, 2]
+    return (s * (f(1.0) / np.sqrt(sq, dtype=f))[:, None]).astype(f)
+
+
+def shade_primary(hits, material_id, albedo):
+    """primary_hit_display::sample_pixel, gi/primary-hit.cpp:16-30: albedo of the hit triangle, black for a miss."""
+    out = np.zeros((len(hits), 4), np.float32)
+    valid = hits["t"] != FLT_MAX
+    out[valid, 0:3] = np.asarray(albedo, np.float32)[np.asarray(material_id)[hits["ref"][valid]]]
+    return out
+
+
+def shade_local(pos, tri, ns, material_id, albedo, hits, occluded, light_pos, light_col):
+    """local_illumination::sample_pixel, gi/primary-hit.cpp:32-57, with the lambertian BRDF
+    (libgi/material.cpp:17-20) and pointlight::power = 4 pi col (libgi/scene.cpp:216-218)."""
+    f = np.float32
+    out = np.zeros((len(hits), 4), f)
+    lit = np.flatnonzero((hits["t"] != FLT_MAX) & (np.asarray(occluded) == 0))
+    hv = hits[lit]
+    x = hit_points(pos, tri, hv)
+    to_light = (np.asarray(light_pos, f)[None, :] - x).astype(f)
+    sq = (to_light[:, 0] * to_light[:, 0] + to_light[:, 1] * to_light[:, 1]) + to_light[:, 2] * to_light[:, 2]
+    d = np.sqrt(sq, dtype=f)
+    w_i = to_light * (f(1.0) / d)[:, None]
+    n = ns[hv["ref"]]
+    facing = ((n[:, 0] * w_i[:, 0] + n[:, 1] * w_i[:, 1]) + n[:, 2] * w_i[:, 2]) > 0
+    power = (f(4) * PI) * np.asarray(light_col, f)
+    alb = np.asarray(albedo, f)[np.asarray(material_id)[hv["ref"]]]
+    rad = (power[None, :] * (ONE_OVER_PI * alb)) / (d * d)[:, None]
+    rad[~facing] = 0
+    out[lit, 0:3] = rad
+    return out
+
+
+def framebuffer_add(fb, radiance):
+    """framebuffer::add, libgi/framebuffer.cpp:10-18, one sample per pixel: running mean in rgb, count in w."""
+    f = np.float32
+    new_count = (fb[:, 3] + f(1.0)).astype(f)
+    out = np.empty_like(fb)
+    out[:, 0:3] = (fb[:, 0:3] * fb[:, 3:4] + radiance[:, 0:3]) / new_count[:, None]
+    out[:, 3] = new_count
+    return out
+
+
+def framebuffer_rgb8(fb, w, h):
+    """framebuffer::png, libgi/framebuffer.cpp:21-30: clamp, gamma 1/2.2, * 255, truncate, rows flipped."""
+    f = np.float32
+    c = np.clip(fb[:, 0:3].reshape(h, w, 3), f(0), f(1))
+    c = np.power(c, f(1.0 / 2.2), dtype=f) * f(255.0)
+    return c.astype(np.uint8)[::-1].copy()

@@ -144,6 +144,32 @@ int main(int argc, char **argv) {
 		}
 		EXPECT(same_single);
 		orc_bbvh_destroy(o2);
+		// build together with the shading data (vertex normals, material ids, one albedo per material): same tree,
+		// same permutation of the scene's triangle list; an out-of-range material id is refused
+		rtgi_hip::scene sc3;
+		make_soup(sc3, n_tris, 7);
+		for (auto &v : sc3.vertices) v.norm = rtgi_hip::vec3(0, 0, 1);
+		for (size_t i = 0; i < sc3.triangles.size(); ++i) sc3.triangles[i].material_id = (uint32_t)(i & 1);
+		const float albedo[6] = {0.8f, 0.2f, 0.1f, 0.1f, 0.3f, 0.9f};
+		hip_bvh_batch_tracer shaded(false, false);
+		std::istringstream sah8(" sah 8");
+		shaded.core.interprete("bvh", sah8);
+		shaded.core.build(&sc3, albedo, 2);
+		bool same_order = true;
+		for (size_t i = 0; i < sc3.triangles.size(); ++i) same_order = same_order && sc3.triangles[i].a == sc.triangles[i].a;
+		EXPECT(same_order);
+		bool refused = false;
+		try {
+			rtgi_hip::scene sc4;
+			make_soup(sc4, n_tris, 7);
+			for (auto &v : sc4.vertices) v.norm = rtgi_hip::vec3(0, 0, 1);
+			sc4.triangles[3].material_id = 2;
+			hip_bvh_batch_tracer other(true, false);
+			other.core.build(&sc4, albedo, 2);
+		} catch (const std::runtime_error &) {
+			refused = true;
+		}
+		EXPECT(refused);
 		printf("gpu: %d rays, %d hits\n", n_rays, hits);
 	}
 	orc_bbvh_destroy(o);
