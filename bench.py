@@ -44,6 +44,9 @@ def parse_args():
     ap.add_argument("--bvh", default="", help="extra 'bvh ...' commands separated by ';', e.g. 'sah 16'")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N > 1 (nccl = RCCL; gloo only to rehearse the launch on one GPU)")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     ap.add_argument("--presort", default="none", choices=["none", "morton", "octant_morton", "morton_octant", "random"],
                     help="experiment: reorder the bounce batch on the host before the timed region")
     return ap.parse_args()
@@ -162,13 +165,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    device = 0 if args.one_device else local_rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo")
     elif args.gpus != 1:
         raise SystemExit("--gpus %d needs to be launched through torch.distributed.run" % args.gpus)
-    device = local_rank
     torch.cuda.set_device(device)
 
     w = build_workload(args, rank, device)
@@ -199,7 +205,7 @@ def main():
     kernel_total_ms, launches = t.profile_end()
     kernel_ms = kernel_total_ms / max(launches, 1)
 
-    stats = torch.tensor([elapsed, float(n)], dtype=torch.float64, device="cuda:%d" % device)
+    stats = torch.tensor([elapsed, float(n)], dtype=torch.float64, device="cuda:%d" % device if args.backend == "nccl" else "cpu")
     if world > 1:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -250,6 +256,13 @@ def main():
                 "algorithmic_bytes_per_ray": round(total_bytes / n, 1),
             },
         }
+        # the drop-in form of the same call: rays and hits in host memory, PCIe both ways inside the call (never `value`)
+        t.closest_hit(w["bounce"])
+        t0 = time.perf_counter()
+        for _ in range(3):
+            t.closest_hit(w["bounce"])
+        out["host_buffer_path"] = {"value": round(3 * n / (time.perf_counter() - t0) / 1e6, 2), "unit": "Mrays/s",
+                                   "note": "rtgi_hip_closest_hit on the same batch from host memory, copies included"}
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args, w)
         print(json.dumps(out), flush=True)
