@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--height", type=int, default=720)
     args = ap.parse_args()
     import torch
-    from raytracing_amd import png, scenes, tracer, wavefront
+    from raytracing_amd import png, scenes, tracer
     s = scenes.load_obj_materials(args.obj)
     kd, ks = s["kd"], s["ks"]
     luma = 0.212671 * kd[:, 0] + 0.715160 * kd[:, 1] + 0.072169 * kd[:, 2]
@@ -45,9 +45,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for sample in range(args.sppx):  # algo local; run
-        jitter = torch.from_numpy(np.stack([wavefront.uniform01(np.arange(w * h), 2 * sample, 0) - 0.5,
-                                            wavefront.uniform01(np.arange(w * h), 2 * sample + 1, 0) - 0.5], 1).astype(np.float32)).cuda()
-        d_rays = t.camera_rays_device(cam_dir, cam_pos, cam_up, 65.0, w, h, d_offsets=jitter)
+        d_rays = t.camera_rays_device(cam_dir, cam_pos, cam_up, 65.0, w, h, d_offsets=t.pixel_offsets_device(w * h, sample))
         t.closest_hit_device(d_rays, d_hits)
         t.any_hit_device(t.shadow_rays_device(d_hits, light_pos), d_occ)
         t.framebuffer_add_device(d_fb, t.shade_local_device(d_hits, d_occ, light_pos, light_col))

@@ -148,6 +148,11 @@ typedef struct rtgi_camera {
 int rtgi_hip_camera_rays_device(rtgi_hip_tracer *h, const rtgi_camera *cam, const float *d_offsets, rtgi_ray *d_rays,
                                 void *stream);
 
+/* The sub-pixel offsets of one sample for n pixels, uniform in [-0.5, 0.5) like the two rng draws per pixel of
+ * gi/primary-hit.cpp:20, from a counter-based generator keyed by (pixel, sample, seed): input for
+ * rtgi_hip_camera_rays_device. d_offsets: n pairs of floats. Needs no build(). */
+int rtgi_hip_pixel_offsets_device(rtgi_hip_tracer *h, uint32_t n, uint32_t sample, uint32_t seed, float *d_offsets, void *stream);
+
 /* Shadow rays of local_illumination::sample_pixel, gi/primary-hit.cpp:43-50, one slot per hit record: origin
  * diff_geom::x (libgi/rt.cpp:9), direction towards light_pos, t_max = distance - 1e-4 (ray::length_exclusive).
  * Slots whose hit record is a miss get an empty ray (t_max < t_min), which any_hit reports as not occluded. */

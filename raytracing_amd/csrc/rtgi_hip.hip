@@ -47,8 +47,8 @@ struct rtgi_hip_tracer {
 	float4 *d_normals = nullptr;  // shading normal and material index by reported id (set_shading)
 	float4 *d_albedo = nullptr;
 	uint32_t n_materials = 0, n_scene_triangles = 0, n_scene_vertices = 0;
-	uint32_t *d_wave_counts = nullptr;
-	size_t wave_counts_cap = 0;
+	uint32_t *d_block_counts = nullptr;
+	size_t block_counts_cap = 0;
 
 	// per-launch kernel timing (profile_begin / profile_end)
 	bool profiling = false;
@@ -68,7 +68,7 @@ struct rtgi_hip_tracer {
 	float reorder_min_pops = 120.0f;
 	std::vector<rtgi_ray> probe_rays;
 	uint32_t node_bytes = 0, tri_bytes = 0;
-	int refill_min = 16, leaf_min = 8;
+	int refill_min = 16, leaf_min = 8, drain_leaf_min = 4;
 	bool top_in_lds = true;
 	uint32_t n_segments = 8;
 	int32_t *d_spill = nullptr;
@@ -137,6 +137,7 @@ int upload(rtgi_hip_tracer *h, const rtgi::SceneView &scene) {
 	if (const char *e = getenv("RTGI_HIP_REFILL_MIN")) h->refill_min = std::max(1, std::min(64, atoi(e)));
 	if (const char *e = getenv("RTGI_HIP_SEGMENTS")) h->n_segments = atoi(e) == 1 ? 1u : 8u;
 	if (const char *e = getenv("RTGI_HIP_TOP_IN_LDS")) h->top_in_lds = atoi(e) != 0;
+	if (const char *e = getenv("RTGI_HIP_DRAIN_LEAF_MIN")) h->drain_leaf_min = std::max(1, std::min(64, atoi(e)));
 	if (const char *e = getenv("RTGI_HIP_LEAF_MIN")) h->leaf_min = std::max(1, std::min(64, atoi(e)));
 	if (!flat.nodes.empty()) HIP_TRY(h, hipMemcpy(h->d_nodes, flat.nodes.data(), flat.nodes.size() * sizeof(float), hipMemcpyHostToDevice));
 	HIP_TRY(h, hipMemcpy(h->d_tris, flat.tris.data(), flat.tris.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -305,13 +306,14 @@ int launch(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint32_t n, void *d_out, 
 #endif
 	a.refill_min = h->refill_min;
 	a.leaf_min = h->leaf_min;
+	a.drain_leaf_min = h->drain_leaf_min;
 	a.top_nodes = h->top_in_lds ? rtgi_dev::TOP_NODES : 0;
 	uint32_t blocks = (n + BLOCK - 1) / BLOCK;
 	if (blocks > h->grid_blocks) blocks = h->grid_blocks;
 	a.spill_stride = blocks * BLOCK;
 	a.order = nullptr;
 	a.seg_bounds = nullptr;
-	if ((h->reorder == 1 || (h->reorder == 2 && h->probe_pops > h->reorder_min_pops)) && n >= h->reorder_min) {
+	if ((h->reorder == 1 || (h->reorder == 2 && h->probe_pops > h->reorder_min_pops)) && n >= h->reorder_min && n < (1u << 31)) {  // (the sort counts in int)
 		int rc = sort_rays(h, d_rays, n, stream);
 		if (rc) return rc;
 		a.order = h->d_sort + 3 * h->sort_cap;
@@ -453,7 +455,7 @@ void rtgi_hip_destroy(rtgi_hip_tracer *h) {
 	if (h->d_counter) (void)hipFree(h->d_counter);
 	if (h->d_stage_rays) (void)hipFree(h->d_stage_rays);
 	if (h->d_stage_out) (void)hipFree(h->d_stage_out);
-	if (h->d_wave_counts) (void)hipFree(h->d_wave_counts);
+	if (h->d_block_counts) (void)hipFree(h->d_block_counts);
 	if (h->d_sort) (void)hipFree(h->d_sort);
 	if (h->d_sort_temp) (void)hipFree(h->d_sort_temp);
 	for (auto &e : h->events) {
@@ -648,6 +650,18 @@ int rtgi_hip_camera_rays_device(rtgi_hip_tracer *h, const rtgi_camera *cam, cons
 	return RTGI_OK;
 }
 
+int rtgi_hip_pixel_offsets_device(rtgi_hip_tracer *h, uint32_t n, uint32_t sample, uint32_t seed, float *d_offsets, void *stream) {
+	if (!h) return RTGI_ERR_INVALID;
+	if (h->device < 0) return fail(h, RTGI_ERR_DEVICE, "host-only handle: needs a GPU");
+	if (n == 0) return RTGI_OK;
+	if (!d_offsets || (reinterpret_cast<uintptr_t>(d_offsets) & 7u)) return fail(h, RTGI_ERR_INVALID, "pixel_offsets: null or misaligned buffer");
+	HIP_TRY(h, hipSetDevice(h->device));
+	hipLaunchKernelGGL(rtgi_dev::pixel_offsets_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (float2 *)d_offsets, n,
+	                   sample, seed);
+	HIP_TRY(h, hipGetLastError());
+	return RTGI_OK;
+}
+
 int rtgi_hip_shadow_rays_device(rtgi_hip_tracer *h, const rtgi_hit *d_hits, uint32_t n, const float light_pos[3],
                                 rtgi_ray *d_shadow, void *stream) {
 	if (!h || !light_pos) return RTGI_ERR_INVALID;
@@ -805,26 +819,25 @@ int rtgi_hip_bounce_rays_device(rtgi_hip_tracer *h, const rtgi_ray *d_rays, cons
 	if (!d_rays || !d_hits || !d_out ||
 	    ((reinterpret_cast<uintptr_t>(d_rays) | reinterpret_cast<uintptr_t>(d_hits) | reinterpret_cast<uintptr_t>(d_out)) & 15u))
 		return fail(h, RTGI_ERR_INVALID, "bounce_rays: null or misaligned buffer");
-	const uint32_t n_waves = (n + 63) / 64;
-	if (n_waves > h->wave_counts_cap) {
-		if (h->d_wave_counts) (void)hipFree(h->d_wave_counts);
-		h->d_wave_counts = nullptr;
-		h->wave_counts_cap = 0;
-		HIP_TRY(h, hipMalloc((void **)&h->d_wave_counts, (size_t)n_waves * sizeof(uint32_t)));
-		h->wave_counts_cap = n_waves;
+	const uint32_t n_blocks = (n + 1023) / 1024;  // one count per 1024-ray block
+	if (n_blocks > h->block_counts_cap) {
+		if (h->d_block_counts) (void)hipFree(h->d_block_counts);
+		h->d_block_counts = nullptr;
+		h->block_counts_cap = 0;
+		HIP_TRY(h, hipMalloc((void **)&h->d_block_counts, (size_t)n_blocks * sizeof(uint32_t)));
+		h->block_counts_cap = n_blocks;
 	}
 	rtgi_dev::BounceArgs a;
 	a.rays = (const float4 *)d_rays;
 	a.hits = (const float4 *)d_hits;
 	a.corners = h->d_corners;
-	a.wave_counts = h->d_wave_counts;
+	a.block_counts = h->d_block_counts;
 	a.out = (float4 *)d_out;
 	a.parent = d_parent;
 	a.n = n, a.seed = seed, a.bounce = bounce;
-	const uint32_t blocks = (n + 255) / 256;
-	hipLaunchKernelGGL(rtgi_dev::bounce_count_kernel, dim3(blocks), dim3(256), 0, st, a);
-	hipLaunchKernelGGL(rtgi_dev::scan_kernel, dim3(1), dim3(1024), 0, st, h->d_wave_counts, n_waves, d_count);
-	hipLaunchKernelGGL(rtgi_dev::bounce_write_kernel, dim3(blocks), dim3(256), 0, st, a);
+	hipLaunchKernelGGL(rtgi_dev::bounce_count_kernel, dim3(n_blocks), dim3(1024), 0, st, a);
+	hipLaunchKernelGGL(rtgi_dev::scan_kernel, dim3(1), dim3(1024), 0, st, h->d_block_counts, n_blocks, d_count);
+	hipLaunchKernelGGL(rtgi_dev::bounce_write_kernel, dim3(n_blocks), dim3(1024), 0, st, a);
 	HIP_TRY(h, hipGetLastError());
 	return RTGI_OK;
 }

@@ -58,6 +58,7 @@ struct TraceArgs {
 	int32_t root_ref;
 	int32_t refill_min;     // refill a wave once this many lanes are idle
 	int32_t leaf_min;       // leave the inner-node loop once this many lanes have left it
+	int32_t drain_leaf_min; // the same once the ray supply is used up
 	int32_t top_nodes;      // 0, or TOP_NODES: visits to the first nodes are served from a copy in LDS
 #ifdef RTGI_DIAG
 	unsigned long long *diag;  // diagnostic build only: 8 counters summed over all waves
@@ -229,7 +230,9 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 			continue;
 		}
 		const bool wave_plain = __ballot(cur != IDLE && !plain) == 0;
-		const int keep_going = max(0, (int)__popcll(busy) - a.leaf_min);
+		// While rays are in supply, lanes that reached a leaf wait for company (the triangle code is long); once the
+		// supply is dry the launch ends with its slowest ray, so nobody waits any more.
+		const int keep_going = max(0, (int)__popcll(busy) - (more ? a.leaf_min : a.drain_leaf_min));
 
 		// ---- inner nodes: every lane standing on an inner node takes one step per iteration; the loop ends
 		// once leaf_min lanes have left it (reached a leaf or finished their ray), or nobody is left --------

@@ -104,25 +104,40 @@ __device__ __forceinline__ float uniform01(uint32_t index, uint32_t stream, uint
 	return (float)(key >> 8) * (1.0f / 16777216.0f);
 }
 
+// Sub-pixel offsets for one sample of every pixel, uniform in [-0.5, 0.5): what the renderer draws from its
+// rng per pixel (gi/primary-hit.cpp:20), here keyed by (pixel, sample, seed) so that a frame is reproducible.
+__global__ __launch_bounds__(256) void pixel_offsets_kernel(float2 *offsets, uint32_t n, uint32_t sample, uint32_t seed) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	offsets[i] = make_float2(uniform01(i, 2u * sample, seed) - 0.5f, uniform01(i, 2u * sample + 1u, seed) - 0.5f);
+}
+
 struct BounceArgs {
 	const float4 *rays;
 	const float4 *hits;
 	const float4 *corners;
-	uint32_t *wave_counts;  // pass 1 out, pass 2 in (after the exclusive scan: offsets)
+	uint32_t *block_counts;  // per 1024 rays: pass 1 out, pass 2 in (after the exclusive scan: offsets)
 	float4 *out;
 	uint32_t *parent;  // optional: index of the ray each bounce ray continues
 	uint32_t n, seed, bounce;
 };
 
-// Pass 1: how many rays of each wave hit something (ballot + popcount).
-__global__ __launch_bounds__(256) void bounce_count_kernel(BounceArgs a) {
-	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+// Pass 1: how many rays of each 1024-ray block hit something (ballot + popcount per wave, 16 waves per block).
+__global__ __launch_bounds__(1024) void bounce_count_kernel(BounceArgs a) {
+	__shared__ uint32_t s_wave[16];
+	const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
 	const bool valid = i < a.n && a.hits[i].x != FLT_MAX;
 	const unsigned long long m = __ballot(valid);
-	if ((threadIdx.x & 63u) == 0) a.wave_counts[i >> 6] = (uint32_t)__popcll(m);
+	if ((threadIdx.x & 63u) == 0) s_wave[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t sum = 0;
+		for (int k = 0; k < 16; ++k) sum += s_wave[k];
+		a.block_counts[blockIdx.x] = sum;
+	}
 }
 
-// Exclusive scan of the per-wave counts by one workgroup; total[0] receives the sum.
+// Exclusive scan of the per-block counts by one workgroup; total[0] receives the sum.
 __global__ __launch_bounds__(1024) void scan_kernel(uint32_t *counts, uint32_t n, uint32_t *total) {
 	__shared__ uint32_t partial[1024];
 	const uint32_t per = (n + 1023u) / 1024u;
@@ -150,14 +165,19 @@ __global__ __launch_bounds__(1024) void scan_kernel(uint32_t *counts, uint32_t n
 // rays: from the hit point into a cosine-weighted random direction about the geometric normal that faces the
 // incoming ray. (The renderer has no path tracer; this is this backend's definition of the bounce population,
 // mirrored on the host by raytracing_amd/wavefront.py.)
-__global__ __launch_bounds__(256) void bounce_write_kernel(BounceArgs a) {
-	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+__global__ __launch_bounds__(1024) void bounce_write_kernel(BounceArgs a) {
+	__shared__ uint32_t s_wave[16];
+	const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
 	const float4 hit = i < a.n ? a.hits[i] : make_float4(FLT_MAX, 0, 0, 0);
 	const bool valid = i < a.n && hit.x != FLT_MAX;
 	const unsigned long long m = __ballot(valid);
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	if (lane == 0) s_wave[wave] = (uint32_t)__popcll(m);
+	__syncthreads();
 	if (!valid) return;
-	const uint32_t lane = threadIdx.x & 63u;
-	const uint32_t slot = a.wave_counts[i >> 6] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+	uint32_t before = a.block_counts[blockIdx.x];
+	for (uint32_t k = 0; k < wave; ++k) before += s_wave[k];
+	const uint32_t slot = before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 	float x, y, z;
 	float4 A, B, C;
 	hit_point(a.corners, hit, x, y, z, A, B, C);

@@ -27,7 +27,7 @@ EXPORTS = [
     "rtgi_hip_incoherent_ray_cost",
     "rtgi_hip_get_nodes", "rtgi_hip_get_triangle_order", "rtgi_hip_closest_hit", "rtgi_hip_any_hit",
     "rtgi_hip_closest_hit_device", "rtgi_hip_any_hit_device", "rtgi_hip_camera_rays_device",
-    "rtgi_hip_shadow_rays_device", "rtgi_hip_bounce_rays_device", "rtgi_hip_set_shading",
+    "rtgi_hip_pixel_offsets_device", "rtgi_hip_shadow_rays_device", "rtgi_hip_bounce_rays_device", "rtgi_hip_set_shading",
     "rtgi_hip_shade_primary_device", "rtgi_hip_shade_local_device", "rtgi_hip_framebuffer_add_device",
     "rtgi_hip_framebuffer_rgb8_device", "rtgi_hip_profile_begin", "rtgi_hip_profile_end",
     "rtgi_hip_last_error",
@@ -76,6 +76,7 @@ def lib():
         L.rtgi_hip_camera_rays_device.argtypes = [vp, vp, vp, vp, vp]
         L.rtgi_hip_shadow_rays_device.argtypes = [vp, vp, u32, vp, vp, vp]
         L.rtgi_hip_bounce_rays_device.argtypes = [vp, vp, vp, u32, u32, u32, vp, vp, vp, vp]
+        L.rtgi_hip_pixel_offsets_device.argtypes = [vp, u32, u32, u32, vp, vp]
         L.rtgi_hip_set_shading.argtypes = [vp, vp, sz, u32, vp, sz, u32, vp, u32]
         L.rtgi_hip_shade_primary_device.argtypes = [vp, vp, u32, vp, vp]
         L.rtgi_hip_shade_local_device.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp]
@@ -220,6 +221,14 @@ class HipBvhTracer:
         self._check(lib().rtgi_hip_camera_rays_device(self._h, C.byref(cam), d_offsets.data_ptr() if d_offsets is not None else None,
                                                       d_rays.data_ptr(), self._stream(stream)))
         return d_rays
+
+    def pixel_offsets_device(self, n, sample, seed=0, stream=None):
+        """Sub-pixel offsets of one sample for n pixels in [-0.5, 0.5) -> float32 (n, 2); the values of
+        wavefront.uniform01(pixel, 2 * sample [+ 1], seed) - 0.5."""
+        import torch
+        d_off = torch.empty((n, 2), dtype=torch.float32, device="cuda:%d" % self.device)
+        self._check(lib().rtgi_hip_pixel_offsets_device(self._h, n, sample, seed, d_off.data_ptr(), self._stream(stream)))
+        return d_off
 
     def shadow_rays_device(self, d_hits, light_pos, stream=None):
         """Shadow rays towards a point light, one slot per hit record (gi/primary-hit.cpp:43-50)."""

@@ -61,7 +61,9 @@ def test_frame_of_the_brdf_test_script(layout, tmp_path):
         jitter = np.stack([wavefront.uniform01(np.arange(w * h), 2 * sample, 9) - 0.5,
                            wavefront.uniform01(np.arange(w * h), 2 * sample + 1, 9) - 0.5], 1).astype(np.float32)
         # GPU: camera rays -> closest_hit -> shadow rays -> any_hit -> shading -> framebuffer
-        d_rays = t.camera_rays_device(CAM["cam_dir"], CAM["cam_pos"], CAM["cam_up"], 65.0, w, h, d_offsets=torch.from_numpy(jitter).cuda())
+        d_jitter = t.pixel_offsets_device(w * h, sample, seed=9)
+        assert np.array_equal(d_jitter.cpu().numpy(), jitter)
+        d_rays = t.camera_rays_device(CAM["cam_dir"], CAM["cam_pos"], CAM["cam_up"], 65.0, w, h, d_offsets=d_jitter)
         d_hits = torch.empty((w * h, 4), dtype=torch.float32, device="cuda")
         t.closest_hit_device(d_rays, d_hits)
         d_shadow = t.shadow_rays_device(d_hits, LIGHT_POS)
