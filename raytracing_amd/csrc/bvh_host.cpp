@@ -12,7 +12,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <exception>
 #include <sstream>
+#include <thread>
 
 namespace rtgi {
 namespace {
@@ -86,10 +88,19 @@ public:
 		for (size_t i = 0; i < boxes.size(); ++i)  // prim::center(), bvh.h:52
 			for (int k = 0; k < 3; ++k) centre[i][k] = (boxes[i].lo[k] + boxes[i].hi[k]) * 0.5f;
 
-		out.nodes.clear();
-		out.nodes.reserve(2 * boxes.size());
-		out.root = split_range(0, (uint32_t)boxes.size(), 0);
-		out.depth = deepest;
+		// The two halves of a range are independent (each call sorts and partitions only its own part of
+		// `slots`), so the first levels of the recursion hand their left half to another thread. Every thread
+		// numbers its nodes from 0 in an arena of its own; joining appends the arenas in the reference's
+		// pre-order (parent, left subtree, right subtree), which gives the node ids a single thread would.
+		unsigned threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+		if (const char *e = getenv("RTGI_HIP_BUILD_THREADS")) threads = (unsigned)std::max(1, std::min(64, atoi(e)));
+		int fork_levels = 0;
+		while ((1u << fork_levels) < threads) ++fork_levels;
+		Arena arena;
+		arena.nodes.reserve(2 * boxes.size());
+		out.root = split_range(0, (uint32_t)boxes.size(), 0, arena, fork_levels);
+		out.nodes = std::move(arena.nodes);
+		out.depth = arena.deepest;
 
 		// commit_shuffled_triangles, bvh2.cpp:172-190: slot -> original triangle id
 		out.order.resize(slots.size());
@@ -105,22 +116,37 @@ private:
 	std::vector<uint32_t> owner;  // primitive box -> triangle
 	std::vector<F3> centre;
 	std::vector<uint32_t> slots;  // the 'index' array the reference sorts
-	uint32_t deepest = 0;
 
-	uint32_t new_node() {
-		out.nodes.emplace_back();
-		rtgi_node56 &n = out.nodes.back();
+	struct Arena {
+		std::vector<rtgi_node56> nodes;
+		uint32_t deepest = 0;
+	};
+	static constexpr uint32_t FORK_MIN = 1u << 14;  // smaller ranges are not worth a thread
+
+	static uint32_t new_node(Arena &a) {
+		a.nodes.emplace_back();
+		rtgi_node56 &n = a.nodes.back();
 		store_box(n.box_l, Bounds());
 		store_box(n.box_r, Bounds());
 		n.link_l = n.link_r = 0;
-		return (uint32_t)out.nodes.size() - 1;
+		return (uint32_t)a.nodes.size() - 1;
 	}
-	uint32_t leaf(uint32_t start, uint32_t end, uint32_t depth) {
-		uint32_t id = new_node();
-		out.nodes[id].link_l = -(int32_t)start;
-		out.nodes[id].link_r = -(int32_t)(end - start);
-		if (depth > deepest) deepest = depth;
+	static uint32_t leaf(uint32_t start, uint32_t end, uint32_t depth, Arena &a) {
+		uint32_t id = new_node(a);
+		a.nodes[id].link_l = -(int32_t)start;
+		a.nodes[id].link_r = -(int32_t)(end - start);
+		if (depth > a.deepest) a.deepest = depth;
 		return id;
+	}
+	// Appends a subtree built in its own arena (root = its node 0); returns the root's id in `a`.
+	static uint32_t append(Arena &a, const Arena &sub) {
+		const int32_t offset = (int32_t)a.nodes.size();
+		for (rtgi_node56 n : sub.nodes) {
+			if (n.link_r >= 0) n.link_l += offset, n.link_r += offset;  // inner node: links are node ids
+			a.nodes.push_back(n);
+		}
+		if (sub.deepest > a.deepest) a.deepest = sub.deepest;
+		return (uint32_t)offset;
 	}
 	Bounds range_bounds(uint32_t start, uint32_t end) const {
 		Bounds b;
@@ -146,8 +172,8 @@ private:
 		return mid;
 	}
 
-	uint32_t split_range(uint32_t start, uint32_t end, uint32_t depth) {
-		if (end - start <= (uint32_t)cfg.max_tris) return leaf(start, end, depth);
+	uint32_t split_range(uint32_t start, uint32_t end, uint32_t depth, Arena &arena, int fork_levels) {
+		if (end - start <= (uint32_t)cfg.max_tris) return leaf(start, end, depth, arena);
 		Bounds all = range_bounds(start, end);
 		F3 ext;
 		int axis = all.longest_axis(ext);
@@ -194,17 +220,40 @@ private:
 			have_child_boxes = true;
 			if (cfg.max_tris > 1)  // K_T = K_I = 1, bvh2.cpp:13-14 and :395-403
 				if ((float)(end - start) < (1 + 1 * (cost_l + cost_r)) && (end - start) <= (uint32_t)cfg.max_tris)
-					return leaf(start, end, depth);
+					return leaf(start, end, depth, arena);
 		}
 
-		uint32_t id = new_node();
-		uint32_t l = split_range(start, mid, depth + 1);
-		uint32_t r = split_range(mid, end, depth + 1);
+		uint32_t id = new_node(arena);
+		uint32_t l, r;
+		if (fork_levels > 0 && end - start >= FORK_MIN) {
+			Arena sub_l, sub_r;
+			std::exception_ptr failure;
+			std::thread other([&]() {
+				try {
+					split_range(start, mid, depth + 1, sub_l, fork_levels - 1);
+				} catch (...) {
+					failure = std::current_exception();
+				}
+			});
+			try {
+				split_range(mid, end, depth + 1, sub_r, fork_levels - 1);
+			} catch (...) {
+				other.join();
+				throw;
+			}
+			other.join();
+			if (failure) std::rethrow_exception(failure);
+			l = append(arena, sub_l);
+			r = append(arena, sub_r);
+		} else {
+			l = split_range(start, mid, depth + 1, arena, 0);
+			r = split_range(mid, end, depth + 1, arena, 0);
+		}
 		if (!have_child_boxes) {
 			left = range_bounds(start, mid);
 			right = range_bounds(mid, end);
 		}
-		rtgi_node56 &n = out.nodes[id];
+		rtgi_node56 &n = arena.nodes[id];
 		n.link_l = (int32_t)l;
 		n.link_r = (int32_t)r;
 		store_box(n.box_l, left);
