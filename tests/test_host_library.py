@@ -162,3 +162,31 @@ def test_statistics_and_export(tmp_path, capfd):
     assert t.interprete("bvh", "export 2 %s" % f)
     text = f.read_text()
     assert text.count("\nf ") + text.startswith("f ") == 6 * 2 * 3   # 3 inner nodes on levels 0-1, 2 boxes each
+
+
+@pytest.mark.parametrize("cmds", [(), ("sm",), ("sah 8", "triangles multiple 4")])
+def test_threaded_build_equals_single_threaded_build(cmds, monkeypatch):
+    # ranges of 2^14 primitives and more fork a thread per half on the first levels; node ids, boxes and the
+    # triangle order must not depend on the number of threads, and must still be the oracle's
+    pos, tri, _ = scenes.soup(100000, seed=4, size=0.3)
+    trees = []
+    for threads in ("1", "2", "7"):
+        monkeypatch.setenv("RTGI_HIP_BUILD_THREADS", threads)
+        t = tracer.HipBvhTracer(layout="indexed", device=-1)
+        for c in cmds:
+            t.interprete("bvh", c)
+        t.build(pos, tri)
+        trees.append((t.nodes().tobytes(), t.triangle_order().tobytes(), t.depth, t.root))
+        t.close()
+    assert trees[0] == trees[1] == trees[2]
+    kw = dict(split="om", planes=0, max_tris=1)
+    for c in cmds:
+        p = c.split()
+        if p[0] == "sm":
+            kw["split"] = "sm"
+        elif p[0] == "sah":
+            kw["split"], kw["planes"] = "sah", int(p[1])
+        elif p[0] == "triangles":
+            kw["max_tris"] = int(p[2])
+    o = orc.Bbvh(pos, tri, layout="indexed", **kw)
+    assert o.nodes().tobytes() == trees[0][0]
