@@ -278,3 +278,30 @@ def test_full_size_soup_properties():
     o = orc.Bbvh(pos, tri, layout="indexed")
     sample = np.arange(0, n, 64)
     assert_hits_equal(hits[sample], o.closest_hit(rays[sample]), "2^20 soup sample")
+
+
+@pytest.mark.parametrize("layout,esc,cmds", [("flat", False, ()), ("indexed", False, ("sah 8", "triangles multiple 2")),
+                                             ("indexed", True, ("sm",))])
+def test_rays_aimed_at_shared_vertices_and_edges(layout, esc, cmds):
+    # meshes with shared vertices and edges: a ray aimed exactly at a vertex or an edge midpoint grazes up to six
+    # triangles, whose tests differ in the last bit or tie exactly; which one wins depends on the visiting order
+    rs = np.random.RandomState(17)
+    for pos, tri, _ in (scenes.cornell(3), scenes.terrain_objects(6000), scenes.sponza_class(9000)):
+        lo, hi = pos.min(0), pos.max(0)
+        n = 12000
+        corners = pos[tri[rs.randint(0, len(tri), n)]]                      # (n, 3, 3)
+        k = rs.randint(0, 3, n)
+        vertex = corners[np.arange(n), k]
+        edge_mid = ((corners[np.arange(n), k] + corners[np.arange(n), (k + 1) % 3]) * np.float32(0.5)).astype(np.float32)
+        target = np.where((rs.rand(n) < 0.5)[:, None], vertex, edge_mid)
+        origin = (lo + rs.rand(n, 3) * (hi - lo)).astype(np.float32)
+        origin[: n // 3] = vertex[rs.permutation(n)[: n // 3]]                 # a third start exactly on a vertex
+        d = (target - origin).astype(np.float32)
+        norm = np.linalg.norm(d, axis=1, keepdims=True)
+        keep = norm[:, 0] > 1e-6
+        rays = np.empty((int(keep.sum()), 8), np.float32)
+        rays[:, 0:3] = origin[keep]
+        rays[:, 3:6] = (d[keep] / norm[keep]).astype(np.float32)
+        rays[:, 6] = 1e-4
+        rays[:, 7] = FLT_MAX
+        _check(pos, tri, rays, layout, esc, cmds)
