@@ -70,6 +70,7 @@ struct rtgi_hip_tracer {
 	uint32_t node_bytes = 0, tri_bytes = 0;
 	int refill_min = 16, leaf_min = 8, drain_leaf_min = 4;
 	bool top_in_lds = true;
+	uint32_t blocks_per_cu = 3;
 	uint32_t n_segments = 8;
 	int32_t *d_spill = nullptr;
 	uint32_t *d_counter = nullptr;
@@ -95,6 +96,28 @@ int fail(rtgi_hip_tracer *h, int code, const std::string &msg) {
 		if (e_ != hipSuccess) return fail(h, RTGI_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
 	} while (0)
 
+// Makes the handle's GPU current for the duration of a call and gives the caller's choice back afterwards (the
+// host application, or PyTorch in this repository's tools, may be working on another device).
+struct DeviceScope {
+	int previous = -1;
+	hipError_t status;
+	explicit DeviceScope(int device) {
+		if (device < 0) {  // host-only handle: nothing to select
+			status = hipSuccess;
+			return;
+		}
+		status = hipGetDevice(&previous);
+		if (status != hipSuccess) previous = -1;
+		status = previous == device ? hipSuccess : hipSetDevice(device);
+	}
+	~DeviceScope() {
+		int now = -1;
+		if (previous >= 0 && hipGetDevice(&now) == hipSuccess && now != previous) (void)hipSetDevice(previous);
+	}
+	DeviceScope(const DeviceScope &) = delete;
+	DeviceScope &operator=(const DeviceScope &) = delete;
+};
+
 void free_device_tree(rtgi_hip_tracer *h) {
 	if (h->d_nodes) (void)hipFree(h->d_nodes);
 	if (h->d_tris) (void)hipFree(h->d_tris);
@@ -109,19 +132,33 @@ void free_device_tree(rtgi_hip_tracer *h) {
 	h->built = false;
 }
 
+// Tuning knobs for experiments; the defaults are the measured optimum on MI355X.
+void read_tunables(rtgi_hip_tracer *h) {
+	auto number = [](const char *name, int lo, int hi, int fallback) {
+		const char *e = getenv(name);
+		return e ? std::max(lo, std::min(hi, atoi(e))) : fallback;
+	};
+	h->blocks_per_cu = (uint32_t)number("RTGI_HIP_BLOCKS_PER_CU", 1, 16, (int)h->blocks_per_cu);
+	h->refill_min = number("RTGI_HIP_REFILL_MIN", 1, 64, h->refill_min);
+	h->leaf_min = number("RTGI_HIP_LEAF_MIN", 1, 64, h->leaf_min);
+	h->drain_leaf_min = number("RTGI_HIP_DRAIN_LEAF_MIN", 1, 64, h->drain_leaf_min);
+	h->n_segments = number("RTGI_HIP_SEGMENTS", 1, 8, 8) == 1 ? 1u : 8u;
+	h->top_in_lds = number("RTGI_HIP_TOP_IN_LDS", 0, 1, 1) != 0;
+	h->reorder = number("RTGI_HIP_REORDER", 0, 2, h->reorder);
+}
+
 int upload(rtgi_hip_tracer *h, const rtgi::SceneView &scene) {
 	rtgi::FlatTree flat;
 	rtgi::flatten_tree(h->tree, scene, h->cfg.layout, flat);
 	if (h->device < 0) return RTGI_OK;
-	HIP_TRY(h, hipSetDevice(h->device));
+	DeviceScope device_scope(h->device);
+	HIP_TRY(h, device_scope.status);
 	free_device_tree(h);
 	hipDeviceProp_t prop;
 	HIP_TRY(h, hipGetDeviceProperties(&prop, h->device));
-	// persistent grid: workgroups of 4 waves, one wave per SIMD each; default 4 per CU = 4 waves per SIMD (the kernel is issue-bound: more resident waves gain nothing
+	// persistent grid: workgroups of 4 waves, one wave per SIMD each, 3 per CU (2 are clearly slower, 4 gain nothing
 	// and leave each lane fewer rays to amortise its drain phase over)
-	uint32_t per_cu = 3;
-	if (const char *e = getenv("RTGI_HIP_BLOCKS_PER_CU")) per_cu = (uint32_t)std::max(1, std::min(16, atoi(e)));
-	h->grid_blocks = (uint32_t)prop.multiProcessorCount * per_cu;
+	h->grid_blocks = (uint32_t)prop.multiProcessorCount * h->blocks_per_cu;
 	// a near-first depth-first walk never has more pending entries than one per level
 	// of the tree's depth (the entry in flight sits in a register, its pending siblings in memory)
 	h->spill_levels = flat.depth > (uint32_t)STACK_LDS ? flat.depth - STACK_LDS : 0;
@@ -134,11 +171,6 @@ int upload(rtgi_hip_tracer *h, const rtgi::SceneView &scene) {
 	HIP_TRY(h, hipMalloc(&h->d_tris, tri_bytes));
 	h->node_bytes = (uint32_t)node_bytes;
 	h->tri_bytes = (uint32_t)tri_bytes;
-	if (const char *e = getenv("RTGI_HIP_REFILL_MIN")) h->refill_min = std::max(1, std::min(64, atoi(e)));
-	if (const char *e = getenv("RTGI_HIP_SEGMENTS")) h->n_segments = atoi(e) == 1 ? 1u : 8u;
-	if (const char *e = getenv("RTGI_HIP_TOP_IN_LDS")) h->top_in_lds = atoi(e) != 0;
-	if (const char *e = getenv("RTGI_HIP_DRAIN_LEAF_MIN")) h->drain_leaf_min = std::max(1, std::min(64, atoi(e)));
-	if (const char *e = getenv("RTGI_HIP_LEAF_MIN")) h->leaf_min = std::max(1, std::min(64, atoi(e)));
 	if (!flat.nodes.empty()) HIP_TRY(h, hipMemcpy(h->d_nodes, flat.nodes.data(), flat.nodes.size() * sizeof(float), hipMemcpyHostToDevice));
 	HIP_TRY(h, hipMemcpy(h->d_tris, flat.tris.data(), flat.tris.size() * sizeof(float), hipMemcpyHostToDevice));
 	HIP_TRY(h, hipMalloc((void **)&h->d_corners, std::max<size_t>(flat.corners.size() * sizeof(float), 48)));
@@ -158,7 +190,6 @@ int upload(rtgi_hip_tracer *h, const rtgi::SceneView &scene) {
 		h->scene_hi[k] = hi[k];
 		h->scene_inv_extent[k] = hi[k] > lo[k] ? 1.0f / (hi[k] - lo[k]) : 0.0f;
 	}
-	if (const char *e = getenv("RTGI_HIP_REORDER")) h->reorder = std::max(0, std::min(2, atoi(e)));
 	h->root_ref = flat.root_ref;
 	h->n_scene_triangles = scene.n_triangles;
 	h->n_scene_vertices = scene.n_vertices;
@@ -266,7 +297,8 @@ int launch(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint32_t n, void *d_out, 
 	if (!d_rays || !d_out) return fail(h, RTGI_ERR_INVALID, "null ray or output buffer");
 	if ((reinterpret_cast<uintptr_t>(d_rays) & 15u) != 0) return fail(h, RTGI_ERR_INVALID, "ray buffer must be 16-byte aligned");
 	if (!ANY && (reinterpret_cast<uintptr_t>(d_out) & 15u) != 0) return fail(h, RTGI_ERR_INVALID, "hit buffer must be 16-byte aligned");
-	HIP_TRY(h, hipSetDevice(h->device));
+	DeviceScope device_scope(h->device);
+	HIP_TRY(h, device_scope.status);
 	TraceArgs a;
 	a.nodes = h->d_nodes;
 	a.tris = h->d_tris;
@@ -373,7 +405,8 @@ int trace_host(rtgi_hip_tracer *h, const rtgi_ray *rays, uint32_t n, void *out) 
 	if (!h->built) return fail(h, RTGI_ERR_NOT_BUILT, "no acceleration structure: call build first");
 	if (n == 0) return RTGI_OK;
 	if (!rays || !out) return fail(h, RTGI_ERR_INVALID, "null ray or output buffer");
-	HIP_TRY(h, hipSetDevice(h->device));
+	DeviceScope device_scope(h->device);
+	HIP_TRY(h, device_scope.status);
 	const size_t out_bytes = (size_t)n * (ANY ? 1 : sizeof(rtgi_hit));
 	int rc = ensure_stage(h, (size_t)n * sizeof(rtgi_ray), out_bytes);
 	if (rc) return rc;
@@ -445,12 +478,13 @@ rtgi_hip_tracer *rtgi_hip_create(int device, int layout, int esc) {
 	h->device = device;
 	h->cfg.layout = layout;
 	h->cfg.esc = esc != 0;
+	read_tunables(h);
 	return h;
 }
 
 void rtgi_hip_destroy(rtgi_hip_tracer *h) {
 	if (!h) return;
-	if (h->device >= 0) (void)hipSetDevice(h->device);
+	DeviceScope device_scope(h->device);
 	free_device_tree(h);
 	if (h->d_counter) (void)hipFree(h->d_counter);
 	if (h->d_stage_rays) (void)hipFree(h->d_stage_rays);
@@ -631,7 +665,8 @@ int rtgi_hip_camera_rays_device(rtgi_hip_tracer *h, const rtgi_camera *cam, cons
 	if (cam->w <= 0 || cam->h <= 0 || !d_rays || (reinterpret_cast<uintptr_t>(d_rays) & 15u))
 		return fail(h, RTGI_ERR_INVALID, "camera_rays: bad resolution or ray buffer (must be 16-byte aligned)");
 	if ((uint64_t)cam->w * (uint64_t)cam->h > 0x7fffffffull) return fail(h, RTGI_ERR_INVALID, "camera_rays: resolution too large");
-	HIP_TRY(h, hipSetDevice(h->device));
+	DeviceScope device_scope(h->device);
+	HIP_TRY(h, device_scope.status);
 	rtgi_dev::CamArgs a;
 	const float *d = cam->dir, *u = cam->up;
 	// cross(dir, up) and cross(U, dir) with glm's component formulas (libgi/camera.cpp:13-14)
@@ -655,7 +690,8 @@ int rtgi_hip_pixel_offsets_device(rtgi_hip_tracer *h, uint32_t n, uint32_t sampl
 	if (h->device < 0) return fail(h, RTGI_ERR_DEVICE, "host-only handle: needs a GPU");
 	if (n == 0) return RTGI_OK;
 	if (!d_offsets || (reinterpret_cast<uintptr_t>(d_offsets) & 7u)) return fail(h, RTGI_ERR_INVALID, "pixel_offsets: null or misaligned buffer");
-	HIP_TRY(h, hipSetDevice(h->device));
+	DeviceScope device_scope(h->device);
+	HIP_TRY(h, device_scope.status);
 	hipLaunchKernelGGL(rtgi_dev::pixel_offsets_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (float2 *)d_offsets, n,
 	                   sample, seed);
 	HIP_TRY(h, hipGetLastError());
@@ -670,7 +706,8 @@ int rtgi_hip_shadow_rays_device(rtgi_hip_tracer *h, const rtgi_hit *d_hits, uint
 	if (n == 0) return RTGI_OK;
 	if (!d_hits || !d_shadow || ((reinterpret_cast<uintptr_t>(d_hits) | reinterpret_cast<uintptr_t>(d_shadow)) & 15u))
 		return fail(h, RTGI_ERR_INVALID, "shadow_rays: null or misaligned buffer");
-	HIP_TRY(h, hipSetDevice(h->device));
+	DeviceScope device_scope(h->device);
+	HIP_TRY(h, device_scope.status);
 	rtgi_dev::ShadowArgs a;
 	a.hits = (const float4 *)d_hits;
 	a.corners = h->d_corners;
@@ -717,7 +754,8 @@ int rtgi_hip_set_shading(rtgi_hip_tracer *h, const void *vertex_normals, size_t 
 	std::vector<float> albedo((size_t)n_materials * 4, 0.0f);
 	for (uint32_t m = 0; m < n_materials; ++m)
 		for (int k = 0; k < 3; ++k) albedo[(size_t)m * 4 + k] = albedo_rgb[(size_t)m * 3 + k];
-	HIP_TRY(h, hipSetDevice(h->device));
+	DeviceScope device_scope(h->device);
+	HIP_TRY(h, device_scope.status);
 	if (h->d_normals) (void)hipFree(h->d_normals);
 	if (h->d_albedo) (void)hipFree(h->d_albedo);
 	h->d_normals = h->d_albedo = nullptr;
@@ -741,7 +779,8 @@ int shade(rtgi_hip_tracer *h, bool local, const rtgi_hit *d_hits, const uint8_t 
 	if (!d_hits || !d_radiance || ((reinterpret_cast<uintptr_t>(d_hits) | reinterpret_cast<uintptr_t>(d_radiance)) & 15u))
 		return fail(h, RTGI_ERR_INVALID, "shade: null or misaligned buffer");
 	if (local && (!d_occluded || !light_pos || !light_col)) return fail(h, RTGI_ERR_INVALID, "shade_local: null argument");
-	HIP_TRY(h, hipSetDevice(h->device));
+	DeviceScope device_scope(h->device);
+	HIP_TRY(h, device_scope.status);
 	rtgi_dev::ShadeArgs a;
 	a.hits = (const float4 *)d_hits;
 	a.occluded = d_occluded;
@@ -781,7 +820,8 @@ int rtgi_hip_framebuffer_add_device(rtgi_hip_tracer *h, float *d_framebuffer, co
 	if (!d_framebuffer || !d_radiance ||
 	    ((reinterpret_cast<uintptr_t>(d_framebuffer) | reinterpret_cast<uintptr_t>(d_radiance)) & 15u))
 		return fail(h, RTGI_ERR_INVALID, "framebuffer_add: null or misaligned buffer");
-	HIP_TRY(h, hipSetDevice(h->device));
+	DeviceScope device_scope(h->device);
+	HIP_TRY(h, device_scope.status);
 	hipLaunchKernelGGL(rtgi_dev::framebuffer_add_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
 	                   (float4 *)d_framebuffer, (const float4 *)d_radiance, n);
 	HIP_TRY(h, hipGetLastError());
@@ -796,7 +836,8 @@ int rtgi_hip_framebuffer_rgb8_device(rtgi_hip_tracer *h, const float *d_framebuf
 	if ((uint64_t)w * height > 0x7fffffffull) return fail(h, RTGI_ERR_INVALID, "framebuffer_rgb8: image too large");
 	if (!d_framebuffer || !d_rgb || (reinterpret_cast<uintptr_t>(d_framebuffer) & 15u))
 		return fail(h, RTGI_ERR_INVALID, "framebuffer_rgb8: null or misaligned buffer");
-	HIP_TRY(h, hipSetDevice(h->device));
+	DeviceScope device_scope(h->device);
+	HIP_TRY(h, device_scope.status);
 	hipLaunchKernelGGL(rtgi_dev::framebuffer_rgb8_kernel, dim3((w * height + 255) / 256), dim3(256), 0, (hipStream_t)stream,
 	                   (const float4 *)d_framebuffer, w, height, d_rgb);
 	HIP_TRY(h, hipGetLastError());
@@ -810,7 +851,8 @@ int rtgi_hip_bounce_rays_device(rtgi_hip_tracer *h, const rtgi_ray *d_rays, cons
 	if (h->device < 0) return fail(h, RTGI_ERR_DEVICE, "host-only handle: needs a GPU");
 	if (!h->built) return fail(h, RTGI_ERR_NOT_BUILT, "no acceleration structure: call build first");
 	if (!d_count) return fail(h, RTGI_ERR_INVALID, "bounce_rays: d_count is required");
-	HIP_TRY(h, hipSetDevice(h->device));
+	DeviceScope device_scope(h->device);
+	HIP_TRY(h, device_scope.status);
 	hipStream_t st = (hipStream_t)stream;
 	if (n == 0) {
 		HIP_TRY(h, hipMemsetAsync(d_count, 0, sizeof(uint32_t), st));
@@ -853,7 +895,8 @@ int rtgi_hip_profile_begin(rtgi_hip_tracer *h) {
 int rtgi_hip_profile_end(rtgi_hip_tracer *h, double *kernel_ms_total, uint32_t *launches) {
 	if (!h || !kernel_ms_total || !launches) return RTGI_ERR_INVALID;
 	if (h->device < 0) return fail(h, RTGI_ERR_DEVICE, "host-only handle: needs a GPU");
-	HIP_TRY(h, hipSetDevice(h->device));
+	DeviceScope device_scope(h->device);
+	HIP_TRY(h, device_scope.status);
 	double total = 0.0;
 	for (size_t i = 0; i < h->events_used; ++i) {
 		HIP_TRY(h, hipEventSynchronize(h->events[i].second));
