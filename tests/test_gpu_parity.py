@@ -305,3 +305,47 @@ def test_rays_aimed_at_shared_vertices_and_edges(layout, esc, cmds):
         rays[:, 6] = 1e-4
         rays[:, 7] = FLT_MAX
         _check(pos, tri, rays, layout, esc, cmds)
+
+
+def test_multi_million_triangle_deep_tree_mixed_batches():
+    # 2^22 triangles of very uneven size and density, spatial-median split: a tree far deeper than the part of
+    # the traversal stack that lives in LDS (and than the reference's 25 slots). closest_hit and any_hit batches
+    # alternate on one handle; oracle (growable stack) on a sample, including per-ray pop / test counts;
+    # properties on everything.
+    import torch
+    pos, tri, _ = scenes.skewed(1 << 22, seed=5)
+    t = tracer.HipBvhTracer(layout="indexed")
+    _configure(t, ["sm"])
+    t.build(pos, tri)
+    assert t.depth > 40
+    n = 1 << 20
+    rays = _mixed_rays(pos, n, seed=31)
+    d_rays = torch.from_numpy(rays).cuda()
+    halves = (slice(0, n // 2), slice(n // 2, n))
+    d_hits = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+    d_occ = torch.empty(n, dtype=torch.uint8, device="cuda")
+    d_cnt = torch.zeros((n, 2), dtype=torch.int32, device="cuda")
+    for rep in range(2):  # closest, any, closest, any ... on alternating halves, then the other way round
+        for k, part in enumerate(halves):
+            if (k + rep) % 2 == 0:
+                t.closest_hit_device(d_rays[part], d_hits[part], d_cnt[part])
+            else:
+                t.any_hit_device(d_rays[part], d_occ[part])
+    torch.cuda.synchronize()
+    hits = d_hits.cpu().numpy().view(tracer.HIT_DTYPE).reshape(-1)
+    occ = d_occ.cpu().numpy()
+    valid = hits["t"] != FLT_MAX
+    assert (occ == valid).all()
+    assert 0.05 < valid.mean() < 0.95
+    short = rays[valid].copy()
+    short[:, 7] = hits["t"][valid]
+    assert (t.closest_hit(short)["t"] == FLT_MAX).all()
+    o = orc.Bbvh(pos, tri, layout="indexed", split="sm")
+    sample = np.arange(0, n, 16)
+    want, want_counts, max_stack = o.closest_hit(rays[sample], counts=True, max_stack=True)
+    assert_hits_equal(hits[sample], want, "deep tree sample")
+    assert (d_cnt.cpu().numpy().astype(np.uint32)[sample] == want_counts[:, 0:2]).all()
+    assert (occ[sample] == o.any_hit(rays[sample])).all()
+    # (depth 63 selects the kernel variant with the spill area; these rays pile up far fewer pending nodes than the
+    # tree is deep -- the chain-shaped scene above is the one that fills the spill area)
+    assert 8 <= max_stack.max() <= t.depth
