@@ -133,6 +133,20 @@ int rtgi_hip_closest_hit_device(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint
 int rtgi_hip_any_hit_device(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint32_t n, uint8_t *d_occluded,
                             uint32_t *d_counts, void *stream);
 
+/* Several batches in one launch (no counterpart in the reference, whose batch adapter takes one buffer at a
+ * time, libgi/wavefront-rt.h:67-80): up to 8 batches of rays on the GPU, each either a closest_hit batch (d_out:
+ * rtgi_hit per ray) or an any_hit batch (d_out: one byte per ray). Results are those of the single calls; what is
+ * gained is that the batches share one ray supply, so the lanes that the end of one batch leaves idle work on the
+ * others (e.g. the shadow rays and the bounce rays of one sample). Empty batches are allowed. */
+enum { RTGI_BATCH_CLOSEST_HIT = 0, RTGI_BATCH_ANY_HIT = 1 };
+typedef struct rtgi_batch {
+	const rtgi_ray *d_rays;
+	void *d_out;
+	uint32_t n;
+	uint32_t kind;
+} rtgi_batch;
+int rtgi_hip_trace_batches_device(rtgi_hip_tracer *h, const rtgi_batch *batches, uint32_t n_batches, void *stream);
+
 /* ---- ray populations around the tracer, produced on the GPU (the wavefront pipeline's other stages) ---- */
 
 /* struct camera, libgi/camera.h:7-25 (near_w / near_h are derived from fovy, w, h as update_frustum does). */

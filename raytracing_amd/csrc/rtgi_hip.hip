@@ -240,9 +240,17 @@ hipError_t debug_sync(rtgi_hip_tracer *h, const char *stage, hipStream_t stream)
 	return e;
 }
 
-// Sorts the batch by the key of ray_keys_kernel: the permutation ends up in the fourth quarter of d_sort, the
-// octant boundaries behind the ray counters. Buffers grow on demand and are kept.
-int sort_rays(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint32_t n, hipStream_t stream) {
+struct BatchView {
+	const rtgi_ray *rays;
+	uint32_t n;
+	bool any;
+	void *out;
+};
+
+// Sorts the rays of a launch (one or several batches, numbered through) by the key of ray_keys_kernel: the
+// permutation ends up in the fourth quarter of d_sort, the octant boundaries behind the ray counters. Buffers
+// grow on demand and are kept.
+int sort_rays(rtgi_hip_tracer *h, const BatchView *batches, uint32_t n_batches, uint32_t n, hipStream_t stream) {
 	if (n > h->sort_cap) {
 		if (h->d_sort) (void)hipFree(h->d_sort);
 		h->d_sort = nullptr;
@@ -264,7 +272,6 @@ int sort_rays(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint32_t n, hipStream_
 		h->sort_temp_bytes = temp + temp / 4 + 256;
 	}
 	rtgi_dev::KeyArgs k;
-	k.rays = (const float4 *)d_rays;
 	k.keys = keys_in;
 	k.index = index_in;
 	float diag2 = 0.0f;
@@ -273,9 +280,14 @@ int sort_rays(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint32_t n, hipStream_
 		diag2 += (h->scene_hi[c] - h->scene_lo[c]) * (h->scene_hi[c] - h->scene_lo[c]);
 	}
 	k.inv_diagonal = diag2 > 0.0f ? 1.0f / std::sqrt(diag2) : 0.0f;
-	k.n = n;
-	hipLaunchKernelGGL(rtgi_dev::ray_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, k);
-	HIP_TRY(h, debug_sync(h, "ray_keys_kernel", stream));
+	k.first = 0;
+	for (uint32_t b = 0; b < n_batches; ++b) {
+		k.rays = (const float4 *)batches[b].rays;
+		k.n = batches[b].n;
+		hipLaunchKernelGGL(rtgi_dev::ray_keys_kernel, dim3((k.n + 255) / 256), dim3(256), 0, stream, k);
+		HIP_TRY(h, debug_sync(h, "ray_keys_kernel", stream));
+		k.first += k.n;
+	}
 	// Only the KEY_BITS low bits hold the key. (Sorting a bit range that does not start at bit 0 returned wrong
 	// permutations for batches of up to a few 100 k items with rocPRIM of ROCm 7.2.)
 	size_t temp_size = h->sort_temp_bytes;
@@ -288,23 +300,62 @@ int sort_rays(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint32_t n, hipStream_
 	return RTGI_OK;
 }
 
-template <bool ANY>
-int launch(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint32_t n, void *d_out, uint32_t *d_counts, hipStream_t stream) {
+template <int MODE>
+void launch_variant(bool count, bool deep, uint32_t blocks, hipStream_t stream, const TraceArgs &a) {
+	if (count && deep)
+		hipLaunchKernelGGL((trace_kernel<MODE, true, true>), dim3(blocks), dim3(BLOCK), 0, stream, a);
+	else if (count)
+		hipLaunchKernelGGL((trace_kernel<MODE, true, false>), dim3(blocks), dim3(BLOCK), 0, stream, a);
+	else if (deep)
+		hipLaunchKernelGGL((trace_kernel<MODE, false, true>), dim3(blocks), dim3(BLOCK), 0, stream, a);
+	else
+		hipLaunchKernelGGL((trace_kernel<MODE, false, false>), dim3(blocks), dim3(BLOCK), 0, stream, a);
+}
+
+// One traversal launch over one batch or over several (each closest_hit or any_hit). d_counts: single batch only.
+int launch_batches(rtgi_hip_tracer *h, const BatchView *given, uint32_t n_given, uint32_t *d_counts, hipStream_t stream) {
 	if (!h) return RTGI_ERR_INVALID;
 	if (h->device < 0) return fail(h, RTGI_ERR_DEVICE, "host-only handle: traversal needs a GPU");
 	if (!h->built) return fail(h, RTGI_ERR_NOT_BUILT, "no acceleration structure: call build first");
-	if (n == 0) return RTGI_OK;
-	if (!d_rays || !d_out) return fail(h, RTGI_ERR_INVALID, "null ray or output buffer");
-	if ((reinterpret_cast<uintptr_t>(d_rays) & 15u) != 0) return fail(h, RTGI_ERR_INVALID, "ray buffer must be 16-byte aligned");
-	if (!ANY && (reinterpret_cast<uintptr_t>(d_out) & 15u) != 0) return fail(h, RTGI_ERR_INVALID, "hit buffer must be 16-byte aligned");
+	if (n_given > (uint32_t)rtgi_dev::MAX_BATCHES) return fail(h, RTGI_ERR_INVALID, "at most 8 batches per launch");
+	BatchView batches[rtgi_dev::MAX_BATCHES];
+	uint32_t n_batches = 0;
+	uint64_t total = 0;
+	for (uint32_t b = 0; b < n_given; ++b) {
+		const BatchView &v = given[b];
+		if (v.n == 0) continue;
+		if (!v.rays || !v.out) return fail(h, RTGI_ERR_INVALID, "null ray or output buffer");
+		if ((reinterpret_cast<uintptr_t>(v.rays) & 15u) != 0) return fail(h, RTGI_ERR_INVALID, "ray buffer must be 16-byte aligned");
+		if (!v.any && (reinterpret_cast<uintptr_t>(v.out) & 15u) != 0) return fail(h, RTGI_ERR_INVALID, "hit buffer must be 16-byte aligned");
+		batches[n_batches++] = v;
+		total += v.n;
+	}
+	if (n_batches == 0) return RTGI_OK;
+	if (total > 0xfffffff0ull) return fail(h, RTGI_ERR_INVALID, "too many rays in one launch");
+	if (n_batches > 1 && d_counts) return fail(h, RTGI_ERR_INVALID, "per-ray counts are available for single batches only");
+	const uint32_t n = (uint32_t)total;
 	DeviceScope device_scope(h->device);
 	HIP_TRY(h, device_scope.status);
 	TraceArgs a;
+	memset(&a, 0, sizeof(a));
 	a.nodes = h->d_nodes;
 	a.tris = h->d_tris;
-	a.rays = (const float4 *)d_rays;
-	a.hits = ANY ? nullptr : (float4 *)d_out;
-	a.occluded = ANY ? (uint8_t *)d_out : nullptr;
+	const int mode = n_batches > 1 ? 2 : (batches[0].any ? 1 : 0);
+	if (mode == 2) {
+		a.n_batches = n_batches;
+		uint32_t begin = 0;
+		for (uint32_t b = 0; b < n_batches; ++b) {
+			a.batch_begin[b] = begin;
+			a.batch_rays[b] = (const float4 *)batches[b].rays;
+			a.batch_out[b] = batches[b].out;
+			if (batches[b].any) a.batch_any |= 1u << b;
+			begin += batches[b].n;
+		}
+	} else {
+		a.rays = (const float4 *)batches[0].rays;
+		a.hits = mode == 0 ? (float4 *)batches[0].out : nullptr;
+		a.occluded = mode == 1 ? (uint8_t *)batches[0].out : nullptr;
+	}
 	a.counts = d_counts;
 	a.spill = h->d_spill;
 	a.ray_counter = h->d_counter;
@@ -346,7 +397,7 @@ int launch(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint32_t n, void *d_out, 
 	a.order = nullptr;
 	a.seg_bounds = nullptr;
 	if ((h->reorder == 1 || (h->reorder == 2 && h->probe_pops > h->reorder_min_pops)) && n >= h->reorder_min && n < (1u << 31)) {  // (the sort counts in int)
-		int rc = sort_rays(h, d_rays, n, stream);
+		int rc = sort_rays(h, batches, n_batches, n, stream);
 		if (rc) return rc;
 		a.order = h->d_sort + 3 * h->sort_cap;
 		a.seg_bounds = h->d_counter + 8 * rtgi_dev::COUNTER_STRIDE;  // one part per direction octant
@@ -367,17 +418,23 @@ int launch(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint32_t n, void *d_out, 
 	}
 	const bool deep = h->spill_levels > 0;  // the tree is deeper than the LDS part of the stack
 	HIP_TRY(h, hipMemsetAsync(h->d_counter, 0, 8 * rtgi_dev::COUNTER_STRIDE * sizeof(uint32_t), stream));
-	if (d_counts && deep)
-		hipLaunchKernelGGL((trace_kernel<ANY, true, true>), dim3(blocks), dim3(BLOCK), 0, stream, a);
-	else if (d_counts)
-		hipLaunchKernelGGL((trace_kernel<ANY, true, false>), dim3(blocks), dim3(BLOCK), 0, stream, a);
-	else if (deep)
-		hipLaunchKernelGGL((trace_kernel<ANY, false, true>), dim3(blocks), dim3(BLOCK), 0, stream, a);
+	if (mode == 2)
+		launch_variant<2>(false, deep, blocks, stream, a);
+	else if (mode == 1)
+		launch_variant<1>(d_counts != nullptr, deep, blocks, stream, a);
 	else
-		hipLaunchKernelGGL((trace_kernel<ANY, false, false>), dim3(blocks), dim3(BLOCK), 0, stream, a);
+		launch_variant<0>(d_counts != nullptr, deep, blocks, stream, a);
 	if (ev_stop) HIP_TRY(h, hipEventRecord(ev_stop, stream));
-	HIP_TRY(h, debug_sync(h, ANY ? "trace_kernel any_hit" : "trace_kernel closest_hit", stream));
+	HIP_TRY(h, debug_sync(h, mode == 2 ? "trace_kernel batches" : mode == 1 ? "trace_kernel any_hit" : "trace_kernel closest_hit", stream));
 	return RTGI_OK;
+}
+
+template <bool ANY>
+int launch(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint32_t n, void *d_out, uint32_t *d_counts, hipStream_t stream) {
+	if (!h) return RTGI_ERR_INVALID;
+	if (n != 0 && (!d_rays || !d_out)) return fail(h, RTGI_ERR_INVALID, "null ray or output buffer");
+	const BatchView one{d_rays, n, ANY, d_out};
+	return launch_batches(h, &one, 1, d_counts, stream);
 }
 
 int ensure_stage(rtgi_hip_tracer *h, size_t ray_bytes, size_t out_bytes) {
@@ -656,6 +713,20 @@ int rtgi_hip_closest_hit_device(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint
 int rtgi_hip_any_hit_device(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint32_t n, uint8_t *d_occluded,
                             uint32_t *d_counts, void *stream) {
 	return launch<true>(h, d_rays, n, d_occluded, d_counts, (hipStream_t)stream);
+}
+
+int rtgi_hip_trace_batches_device(rtgi_hip_tracer *h, const rtgi_batch *batches, uint32_t n_batches, void *stream) {
+	if (!h) return RTGI_ERR_INVALID;
+	if (n_batches == 0) return RTGI_OK;
+	if (!batches) return fail(h, RTGI_ERR_INVALID, "null batch list");
+	if (n_batches > (uint32_t)rtgi_dev::MAX_BATCHES) return fail(h, RTGI_ERR_INVALID, "at most 8 batches per launch");
+	BatchView views[rtgi_dev::MAX_BATCHES];
+	for (uint32_t b = 0; b < n_batches; ++b) {
+		if (batches[b].kind != RTGI_BATCH_CLOSEST_HIT && batches[b].kind != RTGI_BATCH_ANY_HIT)
+			return fail(h, RTGI_ERR_INVALID, "batch kind must be RTGI_BATCH_CLOSEST_HIT or RTGI_BATCH_ANY_HIT");
+		views[b] = BatchView{batches[b].d_rays, batches[b].n, batches[b].kind == RTGI_BATCH_ANY_HIT, batches[b].d_out};
+	}
+	return launch_batches(h, views, n_batches, nullptr, (hipStream_t)stream);
 }
 
 int rtgi_hip_camera_rays_device(rtgi_hip_tracer *h, const rtgi_camera *cam, const float *d_offsets, rtgi_ray *d_rays,

@@ -35,6 +35,7 @@ constexpr int COUNTER_STRIDE = 32;
 #define RTGI_TOP_NODES 256
 #endif
 constexpr int TOP_NODES = RTGI_TOP_NODES;  // inner nodes 0..TOP_NODES-1 (the top of the breadth-first numbering) are kept in LDS
+constexpr int MAX_BATCHES = 8;
 constexpr int32_t IDLE = INT32_MIN;  // lane has no ray; leaf references are ~slot with slot < 2^30
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -59,6 +60,13 @@ struct TraceArgs {
 	int32_t refill_min;     // refill a wave once this many lanes are idle
 	int32_t leaf_min;       // leave the inner-node loop once this many lanes have left it
 	int32_t drain_leaf_min; // the same once the ray supply is used up
+	// MODE 2 (several batches in one launch): ray i of the launch is ray i - batch_begin[b] of batch b, the last b
+	// with batch_begin[b] <= i; rays / hits / occluded above are unused
+	uint32_t n_batches;
+	uint32_t batch_begin[MAX_BATCHES];
+	const float4 *batch_rays[MAX_BATCHES];
+	void *batch_out[MAX_BATCHES];       // float4 per ray (closest_hit) or one byte per ray (any_hit)
+	uint32_t batch_any;                 // bit b: batch b is an any_hit batch
 	int32_t top_nodes;      // 0, or TOP_NODES: visits to the first nodes are served from a copy in LDS
 #ifdef RTGI_DIAG
 	unsigned long long *diag;  // diagnostic build only: 8 counters summed over all waves
@@ -96,8 +104,10 @@ __device__ __forceinline__ float next_up(float x) {
 	return __uint_as_float((b & 0x80000000u) ? b - 1u : b + 1u);
 }
 
-template <bool ANY, bool COUNT, bool DEEP>
+// MODE 0: closest_hit, 1: any_hit, 2: a launch over several batches, each of one kind or the other.
+template <int MODE, bool COUNT, bool DEEP>
 __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
+	constexpr bool MIXED = MODE == 2;
 	__shared__ int32_t s_stack[STACK_LDS][BLOCK];
 	__shared__ u32x4 s_top[4][TOP_NODES];  // [quad][node]: lanes on different nodes read different 16-byte slots
 	const int tid = threadIdx.x;
@@ -123,6 +133,9 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 	float best_t = FLT_MAX, best_b = 0.0f, best_g = 0.0f;
 	uint32_t best_ref = 0;
 	uint32_t ray_id = 0;
+	bool any_lane = MODE == 1;  // this lane's ray only asks whether anything is hit
+	const float4 *my_rays = a.rays;
+	void *my_out = nullptr;     // MIXED: where this lane's result goes
 	uint32_t n_inner = 0, n_tri = 0;
 	int32_t cur = IDLE;
 	int sp = 0;          // pending entries in memory (the next node to visit is `cur`, in a register)
@@ -147,7 +160,12 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 		return a.spill[(size_t)(sp - STACK_LDS) * a.spill_stride + gl];
 	};
 	auto finish = [&]() {
-		if (ANY)
+		if (MIXED) {
+			if (any_lane)
+				static_cast<uint8_t *>(my_out)[ray_id] = best_ref ? 1 : 0;
+			else
+				static_cast<float4 *>(my_out)[ray_id] = make_float4(best_t, best_b, best_g, __uint_as_float(best_ref));
+		} else if (MODE == 1)
 			a.occluded[ray_id] = best_ref ? 1 : 0;
 		else
 			a.hits[ray_id] = make_float4(best_t, best_b, best_g, __uint_as_float(best_ref));
@@ -207,7 +225,17 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 			// (an index from the order array is trusted only as far as the batch goes)
 			const uint32_t mine = (rank < avail) ? (a.order ? a.order[first + rank] : first + rank) : 0xffffffffu;
 			if (cur == IDLE && mine < n_rays) {
-				const float4 q0 = a.rays[2 * (size_t)mine], q1 = a.rays[2 * (size_t)mine + 1];
+				uint32_t local = mine;
+				if (MIXED) {  // which batch, and which ray of it
+					for (uint32_t b = 0; b < a.n_batches; ++b)
+						if (mine >= a.batch_begin[b]) {
+							local = mine - a.batch_begin[b];
+							my_rays = a.batch_rays[b];
+							my_out = a.batch_out[b];
+							any_lane = (a.batch_any >> b) & 1u;
+						}
+				}
+				const float4 q0 = my_rays[2 * (size_t)local], q1 = my_rays[2 * (size_t)local + 1];
 				ox = q0.x, oy = q0.y, oz = q0.z;
 				dx = q0.w, dy = q1.x, dz = q1.y;
 				t_min = q1.z, t_max = q1.w;
@@ -216,12 +244,12 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 				plain = usable(ix) && usable(iy) && usable(iz) && __builtin_isfinite(ox) && __builtin_isfinite(oy) &&
 				        __builtin_isfinite(oz) && t_min == t_min && t_max == t_max && t_max != __builtin_inff();
 				lim0 = next_up(t_max);
-				ray_id = mine;
+				ray_id = local;
 				best_t = FLT_MAX, best_b = 0.0f, best_g = 0.0f, best_ref = 0;
 				n_inner = n_tri = 0;
 				cur = a.root_ref;
 				sp = 0;
-				lim = ANY ? lim0 : __builtin_fminf(best_t, lim0);
+				lim = any_lane ? lim0 : __builtin_fminf(best_t, lim0);
 			}
 		}
 		const unsigned long long busy = __ballot(cur != IDLE);
@@ -288,7 +316,7 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 							t2 = (fz < t2) ? fz : t2;
 							entry = t1;
 							bool hit = !(t1 > t2) && !(t2 < t_min) && !(t1 > t_max);
-							if (!ANY) hit = hit && t1 < best_t;  // bvh2.cpp:432-433; not in any_hit (:476-477)
+							if (!any_lane) hit = hit && t1 < best_t;  // bvh2.cpp:432-433; not in any_hit (:476-477)
 							return hit;
 						};
 						hl = slab(ax.x, bx.x, ay.x, by.x, az.x, bz.x, dl);
@@ -342,7 +370,7 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 				gamma /= M;
 				tt /= M;
 				if (tt > t_min && tt < t_max && beta > 0 && gamma > 0 && beta + gamma <= 1) {
-					if (ANY) {
+					if (any_lane) {
 						best_ref = 1;
 						done = true;
 					} else if (tt < best_t) {
@@ -388,6 +416,7 @@ struct KeyArgs {
 	float lo[3], hi[3], inv_extent[3];
 	float inv_diagonal;
 	uint32_t n;
+	uint32_t first;  // position of this batch's first ray in the launch: keys and indices go to [first, first + n)
 };
 __device__ __forceinline__ uint32_t spread3(uint32_t v) {  // 6 bits -> every third bit
 	v = (v | (v << 8)) & 0x0000F00Fu;
@@ -425,8 +454,8 @@ __global__ __launch_bounds__(256) void ray_keys_kernel(KeyArgs a) {
 	constexpr float top = (float)((1u << CLASS_BITS) - 1u);
 	const float rel = ray_span(a, q0, q1) * a.inv_diagonal * (top + 1.0f);
 	const uint32_t cls = (uint32_t)top - (uint32_t)__builtin_fminf(__builtin_fmaxf(rel == rel ? rel : 0.0f, 0.0f), top);
-	a.keys[i] = (octant << 21) | (cls << (21 - CLASS_BITS)) | (morton >> (CLASS_BITS - 3));
-	a.index[i] = i;
+	a.keys[a.first + i] = (octant << 21) | (cls << (21 - CLASS_BITS)) | (morton >> (CLASS_BITS - 3));
+	a.index[a.first + i] = a.first + i;
 }
 
 // Positions in the sorted key array where the direction octant changes: the 8 parts of the batch that the 8

@@ -26,7 +26,7 @@ EXPORTS = [
     "rtgi_hip_upload_bvh", "rtgi_hip_num_nodes", "rtgi_hip_num_index", "rtgi_hip_root", "rtgi_hip_depth",
     "rtgi_hip_incoherent_ray_cost",
     "rtgi_hip_get_nodes", "rtgi_hip_get_triangle_order", "rtgi_hip_closest_hit", "rtgi_hip_any_hit",
-    "rtgi_hip_closest_hit_device", "rtgi_hip_any_hit_device", "rtgi_hip_camera_rays_device",
+    "rtgi_hip_closest_hit_device", "rtgi_hip_any_hit_device", "rtgi_hip_trace_batches_device", "rtgi_hip_camera_rays_device",
     "rtgi_hip_pixel_offsets_device", "rtgi_hip_shadow_rays_device", "rtgi_hip_bounce_rays_device", "rtgi_hip_set_shading",
     "rtgi_hip_shade_primary_device", "rtgi_hip_shade_local_device", "rtgi_hip_framebuffer_add_device",
     "rtgi_hip_framebuffer_rgb8_device", "rtgi_hip_profile_begin", "rtgi_hip_profile_end",
@@ -73,6 +73,7 @@ def lib():
         L.rtgi_hip_any_hit.argtypes = [vp, vp, u32, vp]
         L.rtgi_hip_closest_hit_device.argtypes = [vp, vp, u32, vp, vp, vp]
         L.rtgi_hip_any_hit_device.argtypes = [vp, vp, u32, vp, vp, vp]
+        L.rtgi_hip_trace_batches_device.argtypes = [vp, vp, u32, vp]
         L.rtgi_hip_camera_rays_device.argtypes = [vp, vp, vp, vp, vp]
         L.rtgi_hip_shadow_rays_device.argtypes = [vp, vp, u32, vp, vp, vp]
         L.rtgi_hip_bounce_rays_device.argtypes = [vp, vp, vp, u32, u32, u32, vp, vp, vp, vp]
@@ -204,6 +205,19 @@ class HipBvhTracer:
         self._check(lib().rtgi_hip_any_hit_device(
             self._h, d_rays.data_ptr(), n, d_occluded.data_ptr(), d_counts.data_ptr() if d_counts is not None else None,
             self._stream(stream)))
+
+    def trace_batches_device(self, batches, stream=None):
+        """Several batches in one launch: batches = [(d_rays (n, 8) float32, d_out, "closest" | "any"), ...] with d_out
+        float32 (n, 4) for closest_hit and uint8 (n,) for any_hit. Same results as the single calls."""
+        class Batch(C.Structure):
+            _fields_ = [("d_rays", C.c_void_p), ("d_out", C.c_void_p), ("n", C.c_uint32), ("kind", C.c_uint32)]
+        arr = (Batch * max(len(batches), 1))()
+        for i, (d_rays, d_out, kind) in enumerate(batches):
+            if kind not in ("closest", "any"):
+                raise ValueError("batch kind must be 'closest' or 'any'")
+            n = self._check_device_args(d_rays, d_out, 4 if kind == "closest" else 1, None)
+            arr[i] = Batch(d_rays.data_ptr() if n else None, d_out.data_ptr() if n else None, n, 0 if kind == "closest" else 1)
+        self._check(lib().rtgi_hip_trace_batches_device(self._h, arr, len(batches), self._stream(stream)))
 
     # -- ray populations on the device (wavefront stages around the tracer) ---------------------------------
     def camera_rays_device(self, cam_dir, cam_pos, cam_up, fovy, w, h, d_offsets=None, stream=None):

@@ -349,3 +349,41 @@ def test_multi_million_triangle_deep_tree_mixed_batches():
     # (depth 63 selects the kernel variant with the spill area; these rays pile up far fewer pending nodes than the
     # tree is deep -- the chain-shaped scene above is the one that fills the spill area)
     assert 8 <= max_stack.max() <= t.depth
+
+
+@pytest.mark.parametrize("scene,cmds,n", [("soup", (), 150000), ("skewed", ("sm",), 40000)])
+def test_several_batches_in_one_launch(scene, cmds, n):
+    # closest_hit and any_hit batches of different sizes (one of them empty) share one launch; every ray's result
+    # must be what the single calls give, i.e. the oracle's. The large case goes through the ray sort, the small
+    # one (below 2^16 rays in total) does not; the skewed scene uses the kernel variant with the spill area.
+    import torch
+    pos, tri, _ = scenes.soup(30000, seed=3, size=0.2) if scene == "soup" else scenes.skewed(40000, seed=6)
+    t = tracer.HipBvhTracer(layout="indexed")
+    _configure(t, cmds)
+    t.build(pos, tri)
+    assert t.interprete("hip", "reorder on")
+    o = _oracle_for(pos, tri, "indexed", False, cmds)
+    rays = _mixed_rays(pos, n, seed=41)
+    cuts = [0, n // 3, n // 3, n // 2 + 11, n]  # the second batch is empty
+    kinds = ["closest", "any", "any", "closest"]
+    d_all = torch.from_numpy(rays).cuda()
+    batches, outs = [], []
+    for k, kind in enumerate(kinds):
+        part = d_all[cuts[k]:cuts[k + 1]].contiguous()
+        m = part.shape[0]
+        d_out = torch.empty((m, 4), dtype=torch.float32, device="cuda") if kind == "closest" else \
+            torch.full((m,), 7, dtype=torch.uint8, device="cuda")
+        batches.append((part, d_out, kind))
+        outs.append(d_out)
+    t.trace_batches_device(batches)
+    torch.cuda.synchronize()
+    for k, kind in enumerate(kinds):
+        part = rays[cuts[k]:cuts[k + 1]]
+        if kind == "closest":
+            got = outs[k].cpu().numpy().view(tracer.HIT_DTYPE).reshape(-1)
+            assert_hits_equal(got, o.closest_hit(part), "batch %d" % k)
+        else:
+            assert (outs[k].cpu().numpy() == o.any_hit(part)).all(), "batch %d" % k
+    t.trace_batches_device([])  # nothing to do
+    with pytest.raises(tracer.RtgiHipError):
+        t.trace_batches_device(batches * 3)  # more than 8
