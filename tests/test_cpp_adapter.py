@@ -25,3 +25,21 @@ def test_adapter_host_side():
 def test_adapter_on_gpu():
     r = _run("gpu")
     assert "hits" in r.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_wavefront_frame_example(tmp_path):
+    # examples/wavefront_frame.cpp: the whole camera -> trace -> shade -> framebuffer loop from C++ on the C ABI
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "wavefront_frame")
+    assert os.path.exists(exe), "run __graft_entry__.build() (or make -C examples) first"
+    lines = []
+    for k in range(2):
+        out = str(tmp_path / ("frame%d.ppm" % k))
+        r = subprocess.run([exe, "320", "180", "3", out], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr
+        lines.append(r.stdout.strip())
+        data = open(out, "rb").read()
+        assert data.startswith(b"P6\n320 180\n255\n") and len(data) == len(b"P6\n320 180\n255\n") + 320 * 180 * 3
+    lit = float(lines[0].split("lit bytes ")[1].split("%")[0])
+    assert lit > 60.0  # a closed, lit room: most of the image is neither black nor missed
+    assert lines[0].split("checksum ")[1].split(";")[0] == lines[1].split("checksum ")[1].split(";")[0]
