@@ -7,8 +7,9 @@
  *
  * Conventions: every function returns RTGI_OK (0) or a negative RTGI_ERR_* code, never throws and
  * never aborts; rtgi_hip_last_error() gives the text.  Calls on one handle must be serialised by the
- * caller (launches share the handle's traversal scratch); different handles may be used from
- * different host threads.  Pointers named d_* are device pointers on the handle's GPU, all others are
+ * calling threads; different handles may be used from different host threads.  On the GPU, launches of
+ * one handle share its scratch buffers: the library orders them itself, also across streams (a launch
+ * on another stream than the previous one waits for it on the GPU), so they never overlap.  Pointers named d_* are device pointers on the handle's GPU, all others are
  * host pointers.  File:line citations are relative to the reference tree
  * "Assignment 3/rtgi-2021-a03-ref/".
  */

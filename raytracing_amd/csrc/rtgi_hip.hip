@@ -47,6 +47,11 @@ struct rtgi_hip_tracer {
 	float4 *d_normals = nullptr;  // shading normal and material index by reported id (set_shading)
 	float4 *d_albedo = nullptr;
 	uint32_t n_materials = 0, n_scene_triangles = 0, n_scene_vertices = 0;
+	// Launches that use the handle's scratch (ray counters, sort buffers, spill area, block counts) are ordered on
+	// the GPU even when the caller moves from one stream to another: see scratch_begin / scratch_end.
+	hipEvent_t scratch_free = nullptr;
+	hipStream_t scratch_stream = nullptr;
+	bool scratch_used = false;
 	uint32_t *d_block_counts = nullptr;
 	size_t block_counts_cap = 0;
 
@@ -240,6 +245,20 @@ hipError_t debug_sync(rtgi_hip_tracer *h, const char *stage, hipStream_t stream)
 	return e;
 }
 
+// The handle has one set of scratch buffers. Work that uses them on a stream other than the previous one's first
+// waits (on the GPU, not on the host) for the previous one to finish.
+int scratch_begin(rtgi_hip_tracer *h, hipStream_t stream) {
+	if (!h->scratch_free) HIP_TRY(h, hipEventCreateWithFlags(&h->scratch_free, hipEventDisableTiming));
+	if (h->scratch_used && stream != h->scratch_stream) HIP_TRY(h, hipStreamWaitEvent(stream, h->scratch_free, 0));
+	return RTGI_OK;
+}
+int scratch_end(rtgi_hip_tracer *h, hipStream_t stream) {
+	HIP_TRY(h, hipEventRecord(h->scratch_free, stream));
+	h->scratch_stream = stream;
+	h->scratch_used = true;
+	return RTGI_OK;
+}
+
 struct BatchView {
 	const rtgi_ray *rays;
 	uint32_t n;
@@ -336,6 +355,7 @@ int launch_batches(rtgi_hip_tracer *h, const BatchView *given, uint32_t n_given,
 	const uint32_t n = (uint32_t)total;
 	DeviceScope device_scope(h->device);
 	HIP_TRY(h, device_scope.status);
+	if (int rc = scratch_begin(h, stream)) return rc;
 	TraceArgs a;
 	memset(&a, 0, sizeof(a));
 	a.nodes = h->d_nodes;
@@ -425,6 +445,7 @@ int launch_batches(rtgi_hip_tracer *h, const BatchView *given, uint32_t n_given,
 	else
 		launch_variant<0>(d_counts != nullptr, deep, blocks, stream, a);
 	if (ev_stop) HIP_TRY(h, hipEventRecord(ev_stop, stream));
+	if (int rc = scratch_end(h, stream)) return rc;
 	HIP_TRY(h, debug_sync(h, mode == 2 ? "trace_kernel batches" : mode == 1 ? "trace_kernel any_hit" : "trace_kernel closest_hit", stream));
 	return RTGI_OK;
 }
@@ -547,6 +568,7 @@ void rtgi_hip_destroy(rtgi_hip_tracer *h) {
 	if (h->d_stage_rays) (void)hipFree(h->d_stage_rays);
 	if (h->d_stage_out) (void)hipFree(h->d_stage_out);
 	if (h->d_block_counts) (void)hipFree(h->d_block_counts);
+	if (h->scratch_free) (void)hipEventDestroy(h->scratch_free);
 	if (h->d_sort) (void)hipFree(h->d_sort);
 	if (h->d_sort_temp) (void)hipFree(h->d_sort_temp);
 	for (auto &e : h->events) {
@@ -948,11 +970,12 @@ int rtgi_hip_bounce_rays_device(rtgi_hip_tracer *h, const rtgi_ray *d_rays, cons
 	a.out = (float4 *)d_out;
 	a.parent = d_parent;
 	a.n = n, a.seed = seed, a.bounce = bounce;
+	if (int rc = scratch_begin(h, st)) return rc;
 	hipLaunchKernelGGL(rtgi_dev::bounce_count_kernel, dim3(n_blocks), dim3(1024), 0, st, a);
 	hipLaunchKernelGGL(rtgi_dev::scan_kernel, dim3(1), dim3(1024), 0, st, h->d_block_counts, n_blocks, d_count);
 	hipLaunchKernelGGL(rtgi_dev::bounce_write_kernel, dim3(n_blocks), dim3(1024), 0, st, a);
 	HIP_TRY(h, hipGetLastError());
-	return RTGI_OK;
+	return scratch_end(h, st);
 }
 
 int rtgi_hip_profile_begin(rtgi_hip_tracer *h) {

@@ -387,3 +387,28 @@ def test_several_batches_in_one_launch(scene, cmds, n):
     t.trace_batches_device([])  # nothing to do
     with pytest.raises(tracer.RtgiHipError):
         t.trace_batches_device(batches * 3)  # more than 8
+
+
+def test_launches_on_different_streams_do_not_overlap_on_the_scratch():
+    # one handle, calls issued back to back on alternating streams without any synchronisation in between: the
+    # library orders them on the GPU (they share ray counters and sort buffers), so every result is right
+    import torch
+    pos, tri, _ = scenes.soup(30000, seed=3, size=0.2)
+    t = tracer.HipBvhTracer(layout="flat")
+    t.build(pos, tri)
+    assert t.interprete("hip", "reorder on")
+    o = _oracle_for(pos, tri, "flat", False, ())
+    streams = [torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()]
+    sets = [_mixed_rays(pos, 70000 + 5000 * k, seed=50 + k) for k in range(6)]
+    d_sets = [torch.from_numpy(r).cuda() for r in sets]
+    d_hits = [torch.empty((len(r), 4), dtype=torch.float32, device="cuda") for r in sets]
+    d_occ = [torch.empty(len(r), dtype=torch.uint8, device="cuda") for r in sets]
+    torch.cuda.synchronize()
+    for k in range(len(sets)):
+        t.closest_hit_device(d_sets[k], d_hits[k], stream=streams[k % 3])
+        t.any_hit_device(d_sets[k], d_occ[k], stream=streams[(k + 1) % 3])
+    torch.cuda.synchronize()
+    for k, rays in enumerate(sets):
+        got = d_hits[k].cpu().numpy().view(tracer.HIT_DTYPE).reshape(-1)
+        assert_hits_equal(got, o.closest_hit(rays), "set %d" % k)
+        assert (d_occ[k].cpu().numpy() == o.any_hit(rays)).all()
