@@ -12,7 +12,10 @@
 
 #include <cfloat>
 #include <cstdint>
+#include <condition_variable>
 #include <cstring>
+#include <exception>
+#include <mutex>
 #include <sstream>
 #include <stdexcept>
 #include <string>
@@ -228,10 +231,12 @@ private:
 	size_t n_rays = 0;
 };
 
-// Per-ray interface for the renderer's recursive algorithms (gi/primary-hit.cpp:21,36,50). Every call is a
-// one-ray batch on the GPU: correct, and slow by construction -- algorithms that care about speed use the
-// batch tracer above. Calls are serialised by an OpenMP critical section (build with -fopenmp, as the renderer is) because the renderer invokes the tracer from all of
-// its OpenMP threads (libgi/framebuffer.h:41-46).
+// Per-ray interface for the renderer's recursive algorithms (gi/primary-hit.cpp:21,36,50). The renderer calls
+// the tracer from all of its OpenMP threads at once (libgi/framebuffer.h:41-46); a GPU round trip per ray would
+// serialise them, so calls that arrive while a batch is under way are collected and go out together as the next
+// batch: with T host threads a round trip carries up to T rays. Correct for any number of threads (one thread
+// simply gets one-ray batches), and slow by construction next to the batch tracer above -- algorithms that
+// care about speed use that one.
 class hip_bvh_individual_tracer : public individual_ray_tracer {
 public:
 	hip_bvh_individual_tracer(bool indexed = false, bool esc = false, int device = 0) : core(indexed, esc, device) {}
@@ -241,18 +246,74 @@ public:
 	}
 	bool interprete(const std::string &command, std::istringstream &in) override { return core.interprete(command, in); }
 	triangle_intersection closest_hit(const ray &r) override {
-		triangle_intersection out;
-#pragma omp critical(rtgi_hip_single_ray)
-		core.closest_hit(&r, 1, &out);
-		return out;
+		request q{&r, false, {}, false};
+		submit(q);
+		return q.result;
 	}
 	bool any_hit(const ray &r) override {
-		triangle_intersection out;
-#pragma omp critical(rtgi_hip_single_ray)
-		core.any_hit(&r, 1, &out);
-		return out.ref != 0;
+		request q{&r, true, {}, false};
+		submit(q);
+		return q.result.ref != 0;
 	}
 	hip_bvh_core core;
+
+private:
+	struct request {
+		const ray *r;
+		bool any;
+		triangle_intersection result;
+		bool done;
+	};
+	std::mutex guard;
+	std::condition_variable served;
+	std::vector<request *> waiting;
+	bool batch_under_way = false;
+
+	// The first caller that finds no batch under way serves everything that is waiting (its own request
+	// included), then hands over; the others sleep until their request has been served.
+	void submit(request &q) {
+		std::unique_lock<std::mutex> lock(guard);
+		waiting.push_back(&q);
+		while (!q.done) {
+			if (batch_under_way) {
+				served.wait(lock);
+				continue;
+			}
+			batch_under_way = true;
+			std::vector<request *> batch;
+			batch.swap(waiting);
+			lock.unlock();
+			std::exception_ptr failure;
+			try {
+				serve(batch);
+			} catch (...) {
+				failure = std::current_exception();
+			}
+			lock.lock();
+			for (request *p : batch) p->done = true;
+			batch_under_way = false;
+			served.notify_all();
+			if (failure) std::rethrow_exception(failure);
+		}
+	}
+	void serve(const std::vector<request *> &batch) {
+		std::vector<ray> rays;
+		std::vector<triangle_intersection> out;
+		for (int any = 0; any < 2; ++any) {
+			rays.clear();
+			for (const request *p : batch)
+				if (p->any == (any != 0)) rays.push_back(*p->r);
+			if (rays.empty()) continue;
+			out.assign(rays.size(), triangle_intersection());
+			if (any)
+				core.any_hit(rays.data(), rays.size(), out.data());
+			else
+				core.closest_hit(rays.data(), rays.size(), out.data());
+			size_t k = 0;
+			for (request *p : batch)
+				if (p->any == (any != 0)) p->result = out[k++];
+		}
+	}
 };
 
 }  // namespace rtgi_hip

@@ -31,6 +31,7 @@ namespace {
 // ---------------------------------------------------------------------------------------------------
 thread_local std::string g_create_error;
 constexpr size_t PROBE_RAYS = 1u << 15;
+constexpr size_t SMALL_BATCH = 256;  // host batches up to this size skip the staging copies
 
 }  // namespace
 
@@ -87,6 +88,8 @@ struct rtgi_hip_tracer {
 	void *d_stage_rays = nullptr;
 	void *d_stage_out = nullptr;
 	size_t stage_rays_cap = 0, stage_out_cap = 0;
+	// small host batches (the per-ray interface): pinned host memory that the kernel reads and writes directly
+	void *pinned = nullptr, *d_pinned = nullptr;
 };
 
 namespace {
@@ -486,6 +489,20 @@ int trace_host(rtgi_hip_tracer *h, const rtgi_ray *rays, uint32_t n, void *out) 
 	DeviceScope device_scope(h->device);
 	HIP_TRY(h, device_scope.status);
 	const size_t out_bytes = (size_t)n * (ANY ? 1 : sizeof(rtgi_hit));
+	if (n <= SMALL_BATCH) {
+		// a handful of rays: two staged copies would cost more than the traversal; the kernel works on mapped host memory
+		if (!h->pinned) {
+			HIP_TRY(h, hipHostMalloc(&h->pinned, SMALL_BATCH * (sizeof(rtgi_ray) + sizeof(rtgi_hit)), hipHostMallocMapped));
+			HIP_TRY(h, hipHostGetDevicePointer(&h->d_pinned, h->pinned, 0));
+		}
+		memcpy(h->pinned, rays, (size_t)n * sizeof(rtgi_ray));
+		char *out_host = (char *)h->pinned + SMALL_BATCH * sizeof(rtgi_ray), *out_dev = (char *)h->d_pinned + SMALL_BATCH * sizeof(rtgi_ray);
+		int rc = launch<ANY>(h, (const rtgi_ray *)h->d_pinned, n, out_dev, nullptr, nullptr);
+		if (rc) return rc;
+		HIP_TRY(h, hipStreamSynchronize(nullptr));
+		memcpy(out, out_host, out_bytes);
+		return RTGI_OK;
+	}
 	int rc = ensure_stage(h, (size_t)n * sizeof(rtgi_ray), out_bytes);
 	if (rc) return rc;
 	HIP_TRY(h, hipMemcpy(h->d_stage_rays, rays, (size_t)n * sizeof(rtgi_ray), hipMemcpyHostToDevice));
@@ -569,6 +586,7 @@ void rtgi_hip_destroy(rtgi_hip_tracer *h) {
 	if (h->d_stage_out) (void)hipFree(h->d_stage_out);
 	if (h->d_block_counts) (void)hipFree(h->d_block_counts);
 	if (h->scratch_free) (void)hipEventDestroy(h->scratch_free);
+	if (h->pinned) (void)hipHostFree(h->pinned);
 	if (h->d_sort) (void)hipFree(h->d_sort);
 	if (h->d_sort_temp) (void)hipFree(h->d_sort_temp);
 	for (auto &e : h->events) {

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
+#include <omp.h>
 #include <random>
 
 #include "rtgi_hip_tracer.hpp"
@@ -143,6 +144,26 @@ int main(int argc, char **argv) {
 			same_single = same_single && irt->any_hit(rays[i]) == (a2[i] != 0);
 		}
 		EXPECT(same_single);
+		// the way the renderer calls it: from all OpenMP threads at once (libgi/framebuffer.h:41-46); concurrent calls
+		// travel to the GPU together
+		{
+			const int n_mt = 4000 < n_rays ? 4000 : n_rays;
+			std::vector<triangle_intersection> w3(n_mt);
+			std::vector<uint8_t> a3(n_mt);
+			orc_bbvh_closest_hit(o2, rays8.data(), n_mt, w3.data(), nullptr, nullptr, 0);
+			orc_bbvh_any_hit(o2, rays8.data(), n_mt, a3.data(), nullptr, 0);
+			int wrong = 0;
+			const double t0 = omp_get_wtime();
+#pragma omp parallel for schedule(dynamic, 16) num_threads(8) reduction(+ : wrong)
+			for (int i = 0; i < n_mt; ++i) {
+				triangle_intersection is = irt->closest_hit(rays[i]);
+				if (memcmp(&is.t, &w3[i].t, 4) != 0 || is.ref != w3[i].ref) ++wrong;
+				if ((i & 3) == 0 && irt->any_hit(rays[i]) != (a3[i] != 0)) ++wrong;
+			}
+			const double dt = omp_get_wtime() - t0;
+			EXPECT(wrong == 0);
+			printf("per-ray interface from 8 threads: %.0f calls/s\n", 1.25 * n_mt / dt);
+		}
 		orc_bbvh_destroy(o2);
 		// build together with the shading data (vertex normals, material ids, one albedo per material): same tree,
 		// same permutation of the scene's triangle list; an out-of-range material id is refused
