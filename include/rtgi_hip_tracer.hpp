@@ -177,6 +177,7 @@ public:
 		pack(rays, n);
 		occluded.resize(n);
 		check(rtgi_hip_any_hit(h, staged.data(), (uint32_t)n, occluded.data()));
+#pragma omp parallel for schedule(static) if (n > 65536)
 		for (size_t i = 0; i < n; ++i) out[i] = triangle_intersection((unsigned int)occluded[i]);
 	}
 	rtgi_hip_tracer *handle() { return h; }
@@ -196,6 +197,7 @@ private:
 	}
 	void pack(const ray *rays, size_t n) {  // drop the derived member id: 44-byte rays -> 32-byte rays
 		staged.resize(n);
+#pragma omp parallel for schedule(static) if (n > 65536)
 		for (size_t i = 0; i < n; ++i) {
 			const ray &r = rays[i];
 			staged[i] = rtgi_ray{{r.o.x, r.o.y, r.o.z}, {r.d.x, r.d.y, r.d.z}, r.t_min, r.t_max};
