@@ -44,6 +44,7 @@ def parse_args():
     ap.add_argument("--bvh", default="", help="extra 'bvh ...' commands separated by ';', e.g. 'sah 16'")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-host-buffers", action="store_true", help="skip the host-buffer (PCIe-inclusive) leg")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL; gloo only to rehearse the launch on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses GPU 0")
@@ -257,12 +258,13 @@ def main():
             },
         }
         # the drop-in form of the same call: rays and hits in host memory, PCIe both ways inside the call (never `value`)
-        t.closest_hit(w["bounce"])
-        t0 = time.perf_counter()
-        for _ in range(3):
+        if not args.no_host_buffers:
             t.closest_hit(w["bounce"])
-        out["host_buffer_path"] = {"value": round(3 * n / (time.perf_counter() - t0) / 1e6, 2), "unit": "Mrays/s",
-                                   "note": "rtgi_hip_closest_hit on the same batch from host memory, copies included"}
+            t0 = time.perf_counter()
+            for _ in range(3):
+                t.closest_hit(w["bounce"])
+            out["host_buffer_path"] = {"value": round(3 * n / (time.perf_counter() - t0) / 1e6, 2), "unit": "Mrays/s",
+                                       "note": "rtgi_hip_closest_hit on the same batch from host memory, copies included"}
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args, w)
         print(json.dumps(out), flush=True)

@@ -9,7 +9,7 @@ mkdir -p $out
 export TMPDIR=/tmp
 run_pass() {
 	name=$1; shift
-	timeout -s KILL 180 rocprofv3 --pmc "$@" --output-format csv -d $out/$name -o pmc -- python3 bench.py --steps 3 --warmup 1 --no-cpu $BENCH_ARGS > $out/$name.json 2> $out/$name.err
+	timeout -s KILL 180 rocprofv3 --pmc "$@" --output-format csv -d $out/$name -o pmc -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-host-buffers $BENCH_ARGS > $out/$name.json 2> $out/$name.err
 }
 BENCH_ARGS="$*"
 run_pass sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
