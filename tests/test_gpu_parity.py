@@ -412,3 +412,35 @@ def test_launches_on_different_streams_do_not_overlap_on_the_scratch():
         got = d_hits[k].cpu().numpy().view(tracer.HIT_DTYPE).reshape(-1)
         assert_hits_equal(got, o.closest_hit(rays), "set %d" % k)
         assert (d_occ[k].cpu().numpy() == o.any_hit(rays)).all()
+
+
+def test_stored_hit_vectors():
+    # the committed vectors of tests/golden/hit_vectors.npz, without the oracle in the loop
+    import os
+    import torch
+    from tests.util import GOLDEN, HIT_VECTOR_CASES, hit_vector_rays
+    stored = np.load(os.path.join(GOLDEN, "hit_vectors.npz"))
+    for k, (name, layout, split, planes) in enumerate(HIT_VECTOR_CASES):
+        pos, tri, _ = obj_scene(name)
+        rays = hit_vector_rays(pos, k)
+        t = tracer.HipBvhTracer(layout=layout)
+        if split == "sah":
+            assert t.interprete("bvh", "sah %d" % planes)
+        t.build(pos, tri)
+        d_rays = torch.from_numpy(rays).cuda()
+        d_hits = torch.empty((len(rays), 4), dtype=torch.float32, device="cuda")
+        d_occ = torch.empty(len(rays), dtype=torch.uint8, device="cuda")
+        d_cnt = torch.zeros((len(rays), 2), dtype=torch.int32, device="cuda")
+        t.closest_hit_device(d_rays, d_hits, d_cnt)
+        key = "%s/%s/%s" % (name, layout, split)
+        got = d_hits.cpu().numpy().view(np.uint32)
+        want = stored[key + "/hits"]
+        hit = want[:, 0] != np.float32(FLT_MAX).view(np.uint32)
+        assert np.array_equal(got[:, [0, 3]], want[:, [0, 3]]), key          # t bits and triangle id, every ray
+        assert np.array_equal(got[hit], want[hit]), key                       # barycentrics where there is a hit
+        assert np.array_equal(d_cnt.cpu().numpy().astype(np.uint32), stored[key + "/counts"]), key
+        d_cnt.zero_()
+        t.any_hit_device(d_rays, d_occ, d_cnt)
+        assert np.array_equal(d_occ.cpu().numpy(), stored[key + "/occluded"]), key
+        assert np.array_equal(d_cnt.cpu().numpy().astype(np.uint32), stored[key + "/any_counts"]), key
+        t.close()

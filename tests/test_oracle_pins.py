@@ -68,3 +68,20 @@ def test_cam_rays_match_assignment2_dump(golden_dir):
             assert np.allclose(w, rays[i, 3:6], rtol=0, atol=1.5e-6)
             mismatched += 1
     assert mismatched == 0
+
+
+def test_oracle_reproduces_the_stored_hit_vectors():
+    # tests/golden/hit_vectors.npz (written by tests/golden/make_hit_vectors.py): the oracle's own answers, frozen
+    from tests.util import GOLDEN, HIT_VECTOR_CASES, hit_vector_rays, obj_scene
+    stored = np.load(os.path.join(GOLDEN, "hit_vectors.npz"))
+    for k, (name, layout, split, planes) in enumerate(HIT_VECTOR_CASES):
+        pos, tri, _ = obj_scene(name)
+        rays = hit_vector_rays(pos, k)
+        o = orc.Bbvh(pos, tri, layout=layout, split=split, planes=planes)
+        hits, counts = o.closest_hit(rays, counts=True)
+        occluded, any_counts = o.any_hit(rays, counts=True)
+        key = "%s/%s/%s" % (name, layout, split)
+        assert np.array_equal(hits.view(np.uint32).reshape(-1, 4), stored[key + "/hits"]), key
+        assert np.array_equal(counts[:, 0:2], stored[key + "/counts"]), key
+        assert np.array_equal(occluded, stored[key + "/occluded"]), key
+        assert np.array_equal(any_counts[:, 0:2], stored[key + "/any_counts"]), key

@@ -49,3 +49,15 @@ def assert_hits_equal(got, want, what=""):
     for k in ("beta", "gamma"):
         bad = np.flatnonzero(got[k][valid].view(np.uint32) != want[k][valid].view(np.uint32))
         assert bad.size == 0, "%s: %d rays differ in %s" % (what, bad.size, k)
+
+
+# tests/golden/hit_vectors.npz: scenes x tree settings of the stored vectors, and the rays they were made with
+HIT_VECTOR_CASES = [(name, layout, split, planes)
+                    for name in ("tri.obj", "2tri.obj", "brdf-test-noal.obj", "mis.obj")
+                    for layout, split, planes in (("flat", "om", 0), ("indexed", "sah", 4))]
+
+
+def hit_vector_rays(pos, case_index):
+    rays = rays_toward_scene(pos, 3000, 100 + case_index)
+    rays[::7, 7] = np.float32(2.5)  # some with a finite t_max
+    return rays
