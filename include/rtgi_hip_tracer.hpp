@@ -13,9 +13,11 @@
 #include <cfloat>
 #include <cstdint>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <mutex>
+#include <new>
 #include <sstream>
 #include <stdexcept>
 #include <string>
@@ -196,7 +198,7 @@ private:
 		if (rc < 0) throw std::runtime_error(std::string("rtgi_hip: ") + rtgi_hip_last_error(h));
 	}
 	void pack(const ray *rays, size_t n) {  // drop the derived member id: 44-byte rays -> 32-byte rays
-		staged.resize(n);
+		staged.resize(n);  // page-locked memory: the GPU's copy engine reads it directly
 #pragma omp parallel for schedule(static) if (n > 65536)
 		for (size_t i = 0; i < n; ++i) {
 			const ray &r = rays[i];
@@ -205,8 +207,34 @@ private:
 	}
 	rtgi_hip_tracer *h = nullptr;
 	bool indexed;
-	std::vector<rtgi_ray> staged;
-	std::vector<uint8_t> occluded;
+	// std::vector-like buffer in page-locked memory (falls back to ordinary memory if that cannot be had)
+	template <class T>
+	struct pinned_buffer {
+		T *p = nullptr;
+		size_t cap = 0, n = 0;
+		bool locked = false;
+		~pinned_buffer() { release(); }
+		void release() {
+			if (p && locked) rtgi_hip_host_free(p);
+			else free(p);
+			p = nullptr, cap = 0;
+		}
+		void resize(size_t count) {
+			if (count > cap) {
+				release();
+				cap = count + count / 8 + 64;
+				p = static_cast<T *>(rtgi_hip_host_alloc(cap * sizeof(T)));
+				locked = p != nullptr;
+				if (!p) p = static_cast<T *>(malloc(cap * sizeof(T)));
+				if (!p) throw std::bad_alloc();
+			}
+			n = count;
+		}
+		T *data() { return p; }
+		T &operator[](size_t i) { return p[i]; }
+	};
+	pinned_buffer<rtgi_ray> staged;
+	pinned_buffer<uint8_t> occluded;
 };
 
 // The batch interface is the one the GPU is built for: one launch per compute_*() call over n_rays rays.
@@ -215,11 +243,18 @@ private:
 class hip_bvh_batch_tracer : public wf::batch_ray_tracer {
 public:
 	hip_bvh_batch_tracer(bool indexed = false, bool esc = false, int device = 0) : core(indexed, esc, device) {}
+	// The intersection buffer is page-locked while it is the current one (it lives until the next `resolution`
+	// command, libgi/wavefront-rt.h:36-43), so that hits arrive in it without a staging copy.
 	void set_batch(ray *r, triangle_intersection *is, size_t n) {
+		if (is != intersections || n != n_rays) {
+			unlock_results();
+			locked_results = is && n && rtgi_hip_host_register(is, n * sizeof(triangle_intersection)) == RTGI_OK;
+		}
 		rays = r;
 		intersections = is;
 		n_rays = n;
 	}
+	~hip_bvh_batch_tracer() { unlock_results(); }
 	void build(rtgi_hip::scene *s) override {
 		this->scene = s;
 		core.build(s);
@@ -230,7 +265,12 @@ public:
 	hip_bvh_core core;
 
 private:
+	void unlock_results() {
+		if (locked_results) rtgi_hip_host_unregister(intersections);
+		locked_results = false;
+	}
 	size_t n_rays = 0;
+	bool locked_results = false;
 };
 
 // Per-ray interface for the renderer's recursive algorithms (gi/primary-hit.cpp:21,36,50). The renderer calls

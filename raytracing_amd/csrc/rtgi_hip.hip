@@ -755,6 +755,40 @@ int rtgi_hip_any_hit_device(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint32_t
 	return launch<true>(h, d_rays, n, d_occluded, d_counts, (hipStream_t)stream);
 }
 
+void *rtgi_hip_host_alloc(size_t bytes) {
+	void *p = nullptr;
+	if (bytes == 0) return nullptr;
+	const hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+	if (e != hipSuccess) {
+		(void)hipGetLastError();  // the caller falls back to ordinary memory: not an error of a later call
+		g_create_error = std::string("hipHostMalloc: ") + hipGetErrorString(e);
+		return nullptr;
+	}
+	return p;
+}
+
+void rtgi_hip_host_free(void *p) {
+	if (p) (void)hipHostFree(p);
+}
+
+int rtgi_hip_host_register(void *p, size_t bytes) {
+	if (!p || bytes == 0) return RTGI_ERR_INVALID;
+	const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+	if (e == hipSuccess) return RTGI_OK;
+	(void)hipGetLastError();  // optional service: its failure must not surface in a later call
+	g_create_error = std::string("hipHostRegister: ") + hipGetErrorString(e);
+	return RTGI_ERR_DEVICE;
+}
+
+int rtgi_hip_host_unregister(void *p) {
+	if (!p) return RTGI_ERR_INVALID;
+	const hipError_t e = hipHostUnregister(p);
+	if (e == hipSuccess) return RTGI_OK;
+	(void)hipGetLastError();
+	g_create_error = std::string("hipHostUnregister: ") + hipGetErrorString(e);
+	return RTGI_ERR_DEVICE;
+}
+
 int rtgi_hip_trace_batches_device(rtgi_hip_tracer *h, const rtgi_batch *batches, uint32_t n_batches, void *stream) {
 	if (!h) return RTGI_ERR_INVALID;
 	if (n_batches == 0) return RTGI_OK;

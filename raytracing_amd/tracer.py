@@ -26,6 +26,7 @@ EXPORTS = [
     "rtgi_hip_upload_bvh", "rtgi_hip_num_nodes", "rtgi_hip_num_index", "rtgi_hip_root", "rtgi_hip_depth",
     "rtgi_hip_incoherent_ray_cost",
     "rtgi_hip_get_nodes", "rtgi_hip_get_triangle_order", "rtgi_hip_closest_hit", "rtgi_hip_any_hit",
+    "rtgi_hip_host_alloc", "rtgi_hip_host_free", "rtgi_hip_host_register", "rtgi_hip_host_unregister",
     "rtgi_hip_closest_hit_device", "rtgi_hip_any_hit_device", "rtgi_hip_trace_batches_device", "rtgi_hip_camera_rays_device",
     "rtgi_hip_pixel_offsets_device", "rtgi_hip_shadow_rays_device", "rtgi_hip_bounce_rays_device", "rtgi_hip_set_shading",
     "rtgi_hip_shade_primary_device", "rtgi_hip_shade_local_device", "rtgi_hip_framebuffer_add_device",
@@ -73,6 +74,12 @@ def lib():
         L.rtgi_hip_any_hit.argtypes = [vp, vp, u32, vp]
         L.rtgi_hip_closest_hit_device.argtypes = [vp, vp, u32, vp, vp, vp]
         L.rtgi_hip_any_hit_device.argtypes = [vp, vp, u32, vp, vp, vp]
+        L.rtgi_hip_host_alloc.argtypes = [sz]
+        L.rtgi_hip_host_alloc.restype = vp
+        L.rtgi_hip_host_free.argtypes = [vp]
+        L.rtgi_hip_host_free.restype = None
+        L.rtgi_hip_host_register.argtypes = [vp, sz]
+        L.rtgi_hip_host_unregister.argtypes = [vp]
         L.rtgi_hip_trace_batches_device.argtypes = [vp, vp, u32, vp]
         L.rtgi_hip_camera_rays_device.argtypes = [vp, vp, vp, vp, vp]
         L.rtgi_hip_shadow_rays_device.argtypes = [vp, vp, u32, vp, vp, vp]

@@ -191,6 +191,25 @@ int main(int argc, char **argv) {
 			refused = true;
 		}
 		EXPECT(refused);
+		// a frame-sized batch through the renderer's buffers (host memory): rate of compute_closest_hit as a whole
+		{
+			const size_t big = 1u << 20;
+			std::vector<ray> many(big);
+			for (size_t i = 0; i < big; ++i) many[i] = rays[i % rays.size()];
+			std::vector<triangle_intersection> res(big);
+			hb->set_batch(many.data(), res.data(), big);
+			if (rtgi_hip_host_register(many.data(), 4096) == RTGI_OK) rtgi_hip_host_unregister(many.data());
+			else printf("(page-locking caller memory is not available here: %s)\n", rtgi_hip_last_error(nullptr));
+			batch->compute_closest_hit();
+			const double t0 = omp_get_wtime();
+			for (int rep = 0; rep < 3; ++rep) batch->compute_closest_hit();
+			const double dt = (omp_get_wtime() - t0) / 3;
+			bool same_big = true;
+			for (size_t i = 0; i < big; i += 997) same_big = same_big && memcmp(&res[i].t, &want[i % rays.size()].t, 4) == 0 && res[i].ref == want[i % rays.size()].ref;
+			EXPECT(same_big);
+			printf("batch interface on host buffers: %.0f Mrays/s (2^20 rays per call, packing and copies included)\n", big / dt / 1e6);
+			hb->set_batch(rays.data(), got.data(), rays.size());
+		}
 		printf("gpu: %d rays, %d hits\n", n_rays, hits);
 	}
 	orc_bbvh_destroy(o);
