@@ -17,7 +17,11 @@
 //    and an out-of-range index reads zeros instead of faulting;
 //  * the pending-node stack keeps its top in a register and the rest in LDS as [level][lane] (any mix of
 //    depths is conflict-free); trees deeper than STACK_LDS use the DEEP variant, which continues the stack
-//    in a global area sized from the tree depth, so the stack cannot overflow.
+//    in a global area sized from the tree depth, so the stack cannot overflow;
+//  * the first TOP_NODES nodes of the breadth-first numbering, which every ray visits, are read from a copy in
+//    LDS;
+//  * large batches are traced through a permutation (octant, length class, Morton code of the origin), each XCD
+//    starting on the rays of one direction octant, the long rays first.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -42,7 +46,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct TraceArgs {
-	const void *nodes;      // 64 B per inner node, see pack_node() in bvh_host.cpp
+	const void *nodes;      // 64 B per inner node, see flatten_tree() in bvh_host.cpp
 	const void *tris;       // 48 B per leaf-order slot
 	const float4 *rays;     // 32 B per ray: o.xyz d.x | d.yz t_min t_max
 	const uint32_t *order;  // optional: the i-th ray to trace is rays[order[i]] (spatially sorted batches)
