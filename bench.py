@@ -251,6 +251,8 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": _measured_traffic(args.workload),
+                "traffic_GBs": (round(_measured_traffic(args.workload) / (kernel_ms * 1e-3) / 1e9, 1)
+                                if _measured_traffic(args.workload) else None),
                 "kernel": "rtgi_dev::trace_kernel<closest_hit> (ray sort and counter reset excluded)",
                 "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": int(total_bytes),
