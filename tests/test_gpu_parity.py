@@ -444,3 +444,33 @@ def test_stored_hit_vectors():
         assert np.array_equal(d_occ.cpu().numpy(), stored[key + "/occluded"]), key
         assert np.array_equal(d_cnt.cpu().numpy().astype(np.uint32), stored[key + "/any_counts"]), key
         t.close()
+
+
+def test_degenerate_triangles_and_pathological_rays():
+    # zero-area and collinear triangles (M = 0 in Cramer's rule: inf / NaN, which every comparison rejects,
+    # libgi/intersect.h:43-60), duplicated triangles (exact ties), and rays the renderer would never build on purpose:
+    # zero direction, NaN / inf components, empty and inverted intervals, t_max = +inf. Nothing may hang or fault and
+    # every answer must be the oracle's.
+    rs = np.random.RandomState(23)
+    pos, tri, _ = scenes.soup(6000, seed=12, size=0.4)
+    pos = pos.copy()
+    v = pos.reshape(-1, 3, 3)
+    v[0:200, 1] = v[0:200, 0]                                  # two corners coincide
+    v[200:400, 2] = (v[200:400, 0] + v[200:400, 1]) * 0.5      # collinear
+    v[400:600] = v[400:600, 0:1]                               # a point
+    v[600:900] = v[900:1200]                                   # exact duplicates of other triangles
+    pos = v.reshape(-1, 3)
+    n = 30000
+    rays = _mixed_rays(pos, n, seed=77)
+    k = rs.randint(0, 12, n)
+    rays[k == 0, 3:6] = 0.0                                    # no direction at all: id = inf everywhere
+    rays[k == 1, 3] = np.nan
+    rays[k == 2, 0] = np.inf
+    rays[k == 3, 7] = np.inf                                   # unbounded ray (not FLT_MAX)
+    rays[k == 4, 6], rays[k == 4, 7] = 5.0, 1.0                # inverted interval
+    rays[k == 5, 6] = np.nan
+    rays[k == 6, 7] = np.nan
+    rays[k == 7, 3:6] *= np.float32(1e-30)                     # unnormalised, tiny: id overflows towards inf
+    rays[k == 8, 6] = -1.0                                     # may hit behind the origin
+    for layout, esc, cmds in (("flat", False, ()), ("indexed", False, ("sah 8", "triangles multiple 3")), ("indexed", False, ("sm",))):
+        _check(pos, tri, rays, layout, esc, cmds)
