@@ -474,3 +474,12 @@ def test_degenerate_triangles_and_pathological_rays():
     rays[k == 8, 6] = -1.0                                     # may hit behind the origin
     for layout, esc, cmds in (("flat", False, ()), ("indexed", False, ("sah 8", "triangles multiple 3")), ("indexed", False, ("sm",))):
         _check(pos, tri, rays, layout, esc, cmds)
+    # the same rays, three times over, through the sorted path (keys of NaN / inf rays must be harmless)
+    t = tracer.HipBvhTracer(layout="indexed")
+    t.build(pos, tri)
+    assert t.interprete("hip", "reorder on")
+    big = np.concatenate([rays, rays[::-1], rays])
+    o = orc.Bbvh(pos, tri, layout="indexed")
+    want, want_counts = o.closest_hit(big, counts=True)
+    want_any, want_any_counts = o.any_hit(big, counts=True)
+    _check_device_path(t, big, want, want_counts, want_any, want_any_counts)
