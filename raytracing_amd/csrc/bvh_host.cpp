@@ -14,6 +14,7 @@
 #include <fstream>
 #include <exception>
 #include <sstream>
+#include <system_error>
 #include <thread>
 
 namespace rtgi {
@@ -218,6 +219,15 @@ private:
 				}
 			}
 			have_child_boxes = true;
+			if (mid <= start || mid >= end) {
+				// No plane was accepted: the range's box has no surface (all primitives in one point or on one
+				// axis-parallel line), so every cost is NaN or inf and never below the best so far. The reference
+				// would recurse into an empty range here and stop at its assert (bvh2.cpp:302); split at the
+				// object median instead, which always makes progress.
+				sort_by_centre(start, end, axis);
+				mid = start + (end - start) / 2;
+				have_child_boxes = false;
+			}
 			if (cfg.max_tris > 1)  // K_T = K_I = 1, bvh2.cpp:13-14 and :395-403
 				if ((float)(end - start) < (1 + 1 * (cost_l + cost_r)) && (end - start) <= (uint32_t)cfg.max_tris)
 					return leaf(start, end, depth, arena);
@@ -228,20 +238,28 @@ private:
 		if (fork_levels > 0 && end - start >= FORK_MIN) {
 			Arena sub_l, sub_r;
 			std::exception_ptr failure;
-			std::thread other([&]() {
+			auto left_half = [&]() {
 				try {
 					split_range(start, mid, depth + 1, sub_l, fork_levels - 1);
 				} catch (...) {
 					failure = std::current_exception();
 				}
-			});
+			};
+			std::thread other;
+			try {
+				other = std::thread(left_half);
+			} catch (const std::system_error &) {  // no thread to be had: this one does both halves
+			}
 			try {
 				split_range(mid, end, depth + 1, sub_r, fork_levels - 1);
 			} catch (...) {
-				other.join();
+				if (other.joinable()) other.join();
 				throw;
 			}
-			other.join();
+			if (other.joinable())
+				other.join();
+			else
+				left_half();
 			if (failure) std::rethrow_exception(failure);
 			l = append(arena, sub_l);
 			r = append(arena, sub_r);

@@ -190,3 +190,26 @@ def test_threaded_build_equals_single_threaded_build(cmds, monkeypatch):
             kw["max_tris"] = int(p[2])
     o = orc.Bbvh(pos, tri, layout="indexed", **kw)
     assert o.nodes().tobytes() == trees[0][0]
+
+
+@pytest.mark.parametrize("cmds", [["sah 4"], ["sah 16", "triangles multiple 3"], ["sm"], ["om"]])
+def test_zero_surface_ranges_terminate(cmds):
+    """Several primitives collapsed into one point, or strung along one axis-parallel line: the range's box has
+    no surface, every SAH cost is NaN or inf and no plane is ever accepted. The reference would recurse into an
+    empty range there (bvh2.cpp:302 asserts); the builder must split such ranges at the object median and end
+    with a well-formed tree that covers every triangle once."""
+    point = np.tile(np.array([[1.0, 2.0, 3.0]], np.float32), (3 * 7, 1))
+    line = np.zeros((3 * 9, 3), np.float32)
+    line[:, 1] = np.repeat(np.arange(9, dtype=np.float32), 3)
+    for pos in (point, line, np.concatenate([point, line])):
+        tri = np.arange(len(pos), dtype=np.uint32).reshape(-1, 3)
+        t = _host("indexed")
+        for c in cmds:
+            assert t.interprete("bvh", c)
+        t.build(pos, tri)
+        nodes, order = t.nodes(), t.triangle_order()
+        assert sorted(order.tolist()) == list(range(len(tri)))
+        leaves = nodes[nodes["link_r"] < 0]
+        assert (-leaves["link_r"]).sum() == len(tri) and (leaves["link_r"] != 0).all()
+        assert len(nodes) == 2 * len(leaves) - 1
+        t.close()
