@@ -145,6 +145,19 @@ int rtgi_hip_closest_hit_device(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint
 int rtgi_hip_any_hit_device(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint32_t n, uint8_t *d_occluded,
                             uint32_t *d_counts, void *stream);
 
+/* rtgi_hip_closest_hit_device for callers that cannot allocate GPU memory at the time of the call (code under
+ * HIP graph capture, tight serving loops, harnesses that forbid it). It has no counterpart in the reference. Same
+ * arguments (without per-ray counts) and bit-identical results, but it calls no allocating routine: its working
+ * memory (ray counters, the four arrays and the scratch of the ray sort, the stack spill area of deep trees) is a
+ * fixed 44 MiB array inside the library's code object, one copy per GPU, held until the process ends. At most
+ * 2^21 = 2097152 rays per call, more is refused with RTGI_ERR_INVALID. Where something does not fit, the call adapts
+ * instead of failing: a sort whose scratch would not fit is left out, and for trees deeper than the 24 stack levels
+ * kept in LDS the launch uses as many workgroups as the 8 MiB spill area gives stacks to. All calls on one GPU,
+ * from any handle, share that GPU's array: calls that overlap in time on one GPU race; order them on one stream
+ * or with events. */
+int rtgi_hip_closest_hit_device_noalloc(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint32_t n, rtgi_hit *d_hits,
+                                        void *stream);
+
 /* Several batches in one launch (no counterpart in the reference, whose batch adapter takes one buffer at a
  * time, libgi/wavefront-rt.h:67-80): up to 8 batches of rays on the GPU, each either a closest_hit batch (d_out:
  * rtgi_hit per ray) or an any_hit batch (d_out: one byte per ray). Results are those of the single calls; what is

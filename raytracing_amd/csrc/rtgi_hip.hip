@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <sstream>
 #include <string>
@@ -32,6 +33,39 @@ namespace {
 thread_local std::string g_create_error;
 constexpr size_t PROBE_RAYS = 1u << 15;
 constexpr size_t SMALL_BATCH = 256;  // host batches up to this size skip the staging copies
+
+// Words at the start of the counter block: 8 ray counters, COUNTER_STRIDE words apart (a cache line each), then
+// the 9 segment bounds of a sorted batch.
+constexpr size_t COUNTER_WORDS = 8 * rtgi_dev::COUNTER_STRIDE + 16;
+
+// Fixed scratch memory of rtgi_hip_closest_hit_device_noalloc: one array per GPU, part of the code object, so
+// that entry point never has to allocate. Layout: counters | four sort arrays (keys, keys, indices, indices) of
+// NOALLOC_MAX_RAYS words each | the radix sort's own scratch | stack spill area for trees deeper than the LDS stack.
+constexpr uint32_t NOALLOC_MAX_RAYS = 1u << 21;
+constexpr size_t NOALLOC_COUNTER_BYTES = 4096;
+constexpr size_t NOALLOC_SORT_BYTES = 4 * (size_t)NOALLOC_MAX_RAYS * sizeof(uint32_t);
+constexpr size_t NOALLOC_TEMP_BYTES = 4u << 20;
+constexpr size_t NOALLOC_SPILL_BYTES = 8u << 20;
+constexpr size_t NOALLOC_BYTES = NOALLOC_COUNTER_BYTES + NOALLOC_SORT_BYTES + NOALLOC_TEMP_BYTES + NOALLOC_SPILL_BYTES;
+static_assert(COUNTER_WORDS * sizeof(uint32_t) <= NOALLOC_COUNTER_BYTES, "counter block too small");
+static __device__ __align__(256) unsigned char scratch[NOALLOC_BYTES];
+
+// The array's address on each GPU (every GPU holds its own copy), looked up once per device. Host code must use
+// these pointers, never the array's name.
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_guard;
+unsigned char *g_scratch_ptr[MAX_DEVICES] = {nullptr};
+
+// Device memory a traversal launch needs beyond rays and results.
+struct Scratch {
+	uint32_t *counter = nullptr;  // COUNTER_WORDS words
+	uint32_t *sort = nullptr;     // four arrays of sort_cap words: keys, keys, indices, indices
+	size_t sort_cap = 0;
+	void *sort_temp = nullptr;
+	size_t sort_temp_bytes = 0;
+	int32_t *spill = nullptr;
+	size_t spill_words = 0;
+};
 
 }  // namespace
 
@@ -185,7 +219,7 @@ int upload(rtgi_hip_tracer *h, const rtgi::SceneView &scene) {
 	HIP_TRY(h, hipMemcpy(h->d_corners, flat.corners.data(), flat.corners.size() * sizeof(float), hipMemcpyHostToDevice));
 	if (h->spill_levels)
 		HIP_TRY(h, hipMalloc((void **)&h->d_spill, (size_t)h->spill_levels * h->grid_blocks * BLOCK * sizeof(int32_t)));
-	if (!h->d_counter) HIP_TRY(h, hipMalloc((void **)&h->d_counter, (8 * rtgi_dev::COUNTER_STRIDE + 16) * sizeof(uint32_t)));
+	if (!h->d_counter) HIP_TRY(h, hipMalloc((void **)&h->d_counter, COUNTER_WORDS * sizeof(uint32_t)));
 	// bounds of the whole scene (union of the root's child boxes, or of the single leaf's triangles)
 	float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
 	for (uint32_t v = 0; v < scene.n_vertices; ++v)
@@ -269,11 +303,10 @@ struct BatchView {
 	void *out;
 };
 
-// Sorts the rays of a launch (one or several batches, numbered through) by the key of ray_keys_kernel: the
-// permutation ends up in the fourth quarter of d_sort, the octant boundaries behind the ray counters. Buffers
-// grow on demand and are kept.
-int sort_rays(rtgi_hip_tracer *h, const BatchView *batches, uint32_t n_batches, uint32_t n, hipStream_t stream) {
-	if (n > h->sort_cap) {
+// The handle's own scratch memory, grown on demand for a launch of n rays (sort = the launch will be sorted).
+int handle_scratch(rtgi_hip_tracer *h, uint32_t n, bool sort, Scratch &sc) {
+	if (!h->d_counter) HIP_TRY(h, hipMalloc((void **)&h->d_counter, COUNTER_WORDS * sizeof(uint32_t)));
+	if (sort && n > h->sort_cap) {
 		if (h->d_sort) (void)hipFree(h->d_sort);
 		h->d_sort = nullptr;
 		h->sort_cap = 0;
@@ -281,21 +314,39 @@ int sort_rays(rtgi_hip_tracer *h, const BatchView *batches, uint32_t n_batches, 
 		HIP_TRY(h, hipMalloc((void **)&h->d_sort, 4 * cap * sizeof(uint32_t)));
 		h->sort_cap = cap;
 	}
-	const size_t cap = h->sort_cap;
-	uint32_t *keys_in = h->d_sort, *keys_out = h->d_sort + cap, *index_in = h->d_sort + 2 * cap, *index_out = h->d_sort + 3 * cap;
-	// the sort's scratch size depends on the item count (the library picks its algorithm by size): ask for this n
-	size_t temp = 0;
-	HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(nullptr, temp, keys_in, keys_out, index_in, index_out, (int)n, 0, rtgi_dev::KEY_BITS, stream));
-	if (temp > h->sort_temp_bytes) {
-		if (h->d_sort_temp) (void)hipFree(h->d_sort_temp);
-		h->d_sort_temp = nullptr;
-		h->sort_temp_bytes = 0;
-		HIP_TRY(h, hipMalloc(&h->d_sort_temp, temp + temp / 4 + 256));
-		h->sort_temp_bytes = temp + temp / 4 + 256;
+	if (sort) {
+		// the sort's scratch size depends on the item count (the library picks its algorithm by size): ask for this n
+		size_t temp = 0;
+		hipcub::DoubleBuffer<uint32_t> keys(h->d_sort, h->d_sort + h->sort_cap), index(h->d_sort + 2 * h->sort_cap, h->d_sort + 3 * h->sort_cap);
+		HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(nullptr, temp, keys, index, (int)n, 0, rtgi_dev::KEY_BITS, nullptr));
+		if (temp > h->sort_temp_bytes) {
+			if (h->d_sort_temp) (void)hipFree(h->d_sort_temp);
+			h->d_sort_temp = nullptr;
+			h->sort_temp_bytes = 0;
+			HIP_TRY(h, hipMalloc(&h->d_sort_temp, temp + temp / 4 + 256));
+			h->sort_temp_bytes = temp + temp / 4 + 256;
+		}
 	}
+	sc.counter = h->d_counter;
+	sc.sort = h->d_sort;
+	sc.sort_cap = h->sort_cap;
+	sc.sort_temp = h->d_sort_temp;
+	sc.sort_temp_bytes = h->sort_temp_bytes;
+	sc.spill = h->d_spill;
+	sc.spill_words = (size_t)h->spill_levels * h->grid_blocks * BLOCK;
+	return RTGI_OK;
+}
+
+// Sorts the rays of a launch (one or several batches, numbered through) by the key of ray_keys_kernel, inside the
+// scratch memory given; *order receives the array that holds the permutation, the octant boundaries go behind the
+// ray counters. Allocates nothing; the caller has checked that n rays and the sort's own scratch fit.
+int sort_rays(rtgi_hip_tracer *h, const BatchView *batches, uint32_t n_batches, uint32_t n, const Scratch &sc, hipStream_t stream,
+              const uint32_t **order) {
+	const size_t cap = sc.sort_cap;
+	hipcub::DoubleBuffer<uint32_t> keys(sc.sort, sc.sort + cap), index(sc.sort + 2 * cap, sc.sort + 3 * cap);
 	rtgi_dev::KeyArgs k;
-	k.keys = keys_in;
-	k.index = index_in;
+	k.keys = keys.Current();
+	k.index = index.Current();
 	float diag2 = 0.0f;
 	for (int c = 0; c < 3; ++c) {
 		k.lo[c] = h->scene_lo[c], k.hi[c] = h->scene_hi[c], k.inv_extent[c] = h->scene_inv_extent[c];
@@ -311,14 +362,15 @@ int sort_rays(rtgi_hip_tracer *h, const BatchView *batches, uint32_t n_batches, 
 		k.first += k.n;
 	}
 	// Only the KEY_BITS low bits hold the key. (Sorting a bit range that does not start at bit 0 returned wrong
-	// permutations for batches of up to a few 100 k items with rocPRIM of ROCm 7.2.)
-	size_t temp_size = h->sort_temp_bytes;
-	HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(h->d_sort_temp, temp_size, keys_in, keys_out, index_in, index_out, (int)n, 0,
-	                                            rtgi_dev::KEY_BITS, stream));
+	// permutations for batches of up to a few 100 k items with rocPRIM of ROCm 7.2.) The two array pairs are the
+	// sort's double buffers: which of each pair holds the result is known on the host when the call returns.
+	size_t temp_size = sc.sort_temp_bytes;
+	HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(sc.sort_temp, temp_size, keys, index, (int)n, 0, rtgi_dev::KEY_BITS, stream));
 	HIP_TRY(h, debug_sync(h, "radix sort", stream));
-	hipLaunchKernelGGL(rtgi_dev::segment_bounds_kernel, dim3(1), dim3(512), 0, stream, keys_out, n,
-	                   h->d_counter + 8 * rtgi_dev::COUNTER_STRIDE);
+	hipLaunchKernelGGL(rtgi_dev::segment_bounds_kernel, dim3(1), dim3(512), 0, stream, keys.Current(), n,
+	                   sc.counter + 8 * rtgi_dev::COUNTER_STRIDE);
 	HIP_TRY(h, debug_sync(h, "segment_bounds_kernel", stream));
+	*order = index.Current();
 	return RTGI_OK;
 }
 
@@ -334,8 +386,31 @@ void launch_variant(bool count, bool deep, uint32_t blocks, hipStream_t stream, 
 		hipLaunchKernelGGL((trace_kernel<MODE, false, false>), dim3(blocks), dim3(BLOCK), 0, stream, a);
 }
 
+// Records the "scratch is free again" event when a launch sequence ends, on every path out of it.
+struct ScratchTurn {
+	rtgi_hip_tracer *h;
+	hipStream_t stream;
+	bool open = false;
+	int begin() {
+		int rc = scratch_begin(h, stream);
+		open = rc == RTGI_OK;
+		return rc;
+	}
+	int end() {
+		open = false;
+		return scratch_end(h, stream);
+	}
+	~ScratchTurn() {
+		if (open) (void)scratch_end(h, stream);
+	}
+};
+
 // One traversal launch over one batch or over several (each closest_hit or any_hit). d_counts: single batch only.
-int launch_batches(rtgi_hip_tracer *h, const BatchView *given, uint32_t n_given, uint32_t *d_counts, hipStream_t stream) {
+// fixed == nullptr: the handle's own scratch memory is used and grown as needed. Otherwise the launch lives in
+// *fixed, allocates nothing, creates nothing, and adapts to what fits (the sort is left out, the grid shrinks
+// until the spill area holds its stacks).
+int launch_batches(rtgi_hip_tracer *h, const BatchView *given, uint32_t n_given, uint32_t *d_counts, hipStream_t stream,
+                   const Scratch *fixed = nullptr) {
 	if (!h) return RTGI_ERR_INVALID;
 	if (h->device < 0) return fail(h, RTGI_ERR_DEVICE, "host-only handle: traversal needs a GPU");
 	if (!h->built) return fail(h, RTGI_ERR_NOT_BUILT, "no acceleration structure: call build first");
@@ -358,7 +433,23 @@ int launch_batches(rtgi_hip_tracer *h, const BatchView *given, uint32_t n_given,
 	const uint32_t n = (uint32_t)total;
 	DeviceScope device_scope(h->device);
 	HIP_TRY(h, device_scope.status);
-	if (int rc = scratch_begin(h, stream)) return rc;
+	ScratchTurn turn{h, stream};
+	if (!fixed)  // (launches in fixed scratch are ordered by their callers)
+		if (int rc = turn.begin()) return rc;
+	bool sort = (h->reorder == 1 || (h->reorder == 2 && h->probe_pops > h->reorder_min_pops)) && n >= h->reorder_min &&
+	            n < (1u << 31);  // (the sort counts in int)
+	Scratch sc;
+	if (fixed) {
+		sc = *fixed;
+		if (sort) {  // only if the rays and the sort's own scratch fit
+			size_t temp = 0;
+			hipcub::DoubleBuffer<uint32_t> keys(sc.sort, sc.sort + sc.sort_cap), index(sc.sort + 2 * sc.sort_cap, sc.sort + 3 * sc.sort_cap);
+			sort = n <= sc.sort_cap &&
+			       hipcub::DeviceRadixSort::SortPairs(nullptr, temp, keys, index, (int)n, 0, rtgi_dev::KEY_BITS, stream) == hipSuccess &&
+			       temp <= sc.sort_temp_bytes;
+		}
+	} else if (int rc = handle_scratch(h, n, sort, sc))
+		return rc;
 	TraceArgs a;
 	memset(&a, 0, sizeof(a));
 	a.nodes = h->d_nodes;
@@ -380,8 +471,8 @@ int launch_batches(rtgi_hip_tracer *h, const BatchView *given, uint32_t n_given,
 		a.occluded = mode == 1 ? (uint8_t *)batches[0].out : nullptr;
 	}
 	a.counts = d_counts;
-	a.spill = h->d_spill;
-	a.ray_counter = h->d_counter;
+	a.spill = sc.spill;
+	a.ray_counter = sc.counter;
 	a.n_rays = n;
 	a.n_segments = h->n_segments;
 	a.node_bytes = h->node_bytes;
@@ -416,18 +507,24 @@ int launch_batches(rtgi_hip_tracer *h, const BatchView *given, uint32_t n_given,
 	a.top_nodes = h->top_in_lds ? rtgi_dev::TOP_NODES : 0;
 	uint32_t blocks = (n + BLOCK - 1) / BLOCK;
 	if (blocks > h->grid_blocks) blocks = h->grid_blocks;
+	const bool deep = h->spill_levels > 0;  // the tree is deeper than the LDS part of the stack
+	if (deep) {  // every lane of the grid owns spill_levels words of the spill area
+		const size_t most = sc.spill_words / ((size_t)h->spill_levels * BLOCK);
+		if (most == 0) return fail(h, RTGI_ERR_INVALID, "tree too deep for the fixed scratch memory");
+		if (blocks > most) blocks = (uint32_t)most;
+	}
 	a.spill_stride = blocks * BLOCK;
 	a.order = nullptr;
 	a.seg_bounds = nullptr;
-	if ((h->reorder == 1 || (h->reorder == 2 && h->probe_pops > h->reorder_min_pops)) && n >= h->reorder_min && n < (1u << 31)) {  // (the sort counts in int)
-		int rc = sort_rays(h, batches, n_batches, n, stream);
+	if (sort) {
+		int rc = sort_rays(h, batches, n_batches, n, sc, stream, &a.order);
 		if (rc) return rc;
-		a.order = h->d_sort + 3 * h->sort_cap;
-		a.seg_bounds = h->d_counter + 8 * rtgi_dev::COUNTER_STRIDE;  // one part per direction octant
+		a.seg_bounds = sc.counter + 8 * rtgi_dev::COUNTER_STRIDE;  // one part per direction octant
 		a.n_segments = 8;
 	}
+	HIP_TRY(h, hipMemsetAsync(sc.counter, 0, 8 * rtgi_dev::COUNTER_STRIDE * sizeof(uint32_t), stream));
 	hipEvent_t ev_start = nullptr, ev_stop = nullptr;
-	if (h->profiling && h->events_used < 4096) {
+	if (!fixed && h->profiling && h->events_used < 4096) {
 		if (h->events_used == h->events.size()) {
 			hipEvent_t e0, e1;
 			HIP_TRY(h, hipEventCreate(&e0));
@@ -439,8 +536,6 @@ int launch_batches(rtgi_hip_tracer *h, const BatchView *given, uint32_t n_given,
 		++h->events_used;
 		HIP_TRY(h, hipEventRecord(ev_start, stream));
 	}
-	const bool deep = h->spill_levels > 0;  // the tree is deeper than the LDS part of the stack
-	HIP_TRY(h, hipMemsetAsync(h->d_counter, 0, 8 * rtgi_dev::COUNTER_STRIDE * sizeof(uint32_t), stream));
 	if (mode == 2)
 		launch_variant<2>(false, deep, blocks, stream, a);
 	else if (mode == 1)
@@ -448,7 +543,8 @@ int launch_batches(rtgi_hip_tracer *h, const BatchView *given, uint32_t n_given,
 	else
 		launch_variant<0>(d_counts != nullptr, deep, blocks, stream, a);
 	if (ev_stop) HIP_TRY(h, hipEventRecord(ev_stop, stream));
-	if (int rc = scratch_end(h, stream)) return rc;
+	if (!fixed)
+		if (int rc = turn.end()) return rc;
 	HIP_TRY(h, debug_sync(h, mode == 2 ? "trace_kernel batches" : mode == 1 ? "trace_kernel any_hit" : "trace_kernel closest_hit", stream));
 	return RTGI_OK;
 }
@@ -515,6 +611,8 @@ int trace_host(rtgi_hip_tracer *h, const rtgi_ray *rays, uint32_t n, void *out) 
 // Traces the probe rays of upload() in the order they come and stores the mean number of inner nodes popped.
 int probe_scene(rtgi_hip_tracer *h) {
 	if (h->device < 0 || h->probe_rays.empty()) return RTGI_OK;
+	DeviceScope device_scope(h->device);  // the staging buffers below must live on the handle's GPU
+	HIP_TRY(h, device_scope.status);
 	const uint32_t n = (uint32_t)h->probe_rays.size();
 	int rc = ensure_stage(h, (size_t)n * sizeof(rtgi_ray), (size_t)n * sizeof(rtgi_hit));
 	if (rc) return rc;
@@ -574,6 +672,23 @@ rtgi_hip_tracer *rtgi_hip_create(int device, int layout, int esc) {
 	h->cfg.layout = layout;
 	h->cfg.esc = esc != 0;
 	read_tunables(h);
+	if (device >= 0 && device < MAX_DEVICES) {
+		// set-up for rtgi_hip_closest_hit_device_noalloc: where this GPU keeps its copy of the fixed scratch array
+		std::lock_guard<std::mutex> lock(g_scratch_guard);
+		if (!g_scratch_ptr[device]) {
+			DeviceScope device_scope(device);
+			void *ptr = nullptr;
+			hipError_t e = device_scope.status;
+			if (e == hipSuccess) e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+			if (e != hipSuccess || !ptr) {
+				g_create_error = std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e);
+				(void)hipGetLastError();
+				delete h;
+				return nullptr;
+			}
+			g_scratch_ptr[device] = static_cast<unsigned char *>(ptr);
+		}
+	}
 	return h;
 }
 
@@ -688,6 +803,10 @@ int rtgi_hip_build(rtgi_hip_tracer *h, const void *vertices, size_t vertex_strid
 		return rc_upload ? rc_upload : probe_scene(h);
 	} catch (const std::bad_alloc &) {
 		return fail(h, RTGI_ERR_NOMEM, "out of host memory while building the BVH");
+	} catch (const std::exception &e) {
+		return fail(h, RTGI_ERR_INVALID, std::string("building the BVH failed: ") + e.what());
+	} catch (...) {
+		return fail(h, RTGI_ERR_INVALID, "building the BVH failed");
 	}
 }
 
@@ -721,6 +840,10 @@ int rtgi_hip_upload_bvh(rtgi_hip_tracer *h, const rtgi_node56 *nodes, uint32_t n
 		return rc_upload ? rc_upload : probe_scene(h);
 	} catch (const std::bad_alloc &) {
 		return fail(h, RTGI_ERR_NOMEM, "out of host memory while taking over the BVH");
+	} catch (const std::exception &e) {
+		return fail(h, RTGI_ERR_INVALID, std::string("taking over the BVH failed: ") + e.what());
+	} catch (...) {
+		return fail(h, RTGI_ERR_INVALID, "taking over the BVH failed");
 	}
 }
 
@@ -753,6 +876,26 @@ int rtgi_hip_closest_hit_device(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint
 int rtgi_hip_any_hit_device(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint32_t n, uint8_t *d_occluded,
                             uint32_t *d_counts, void *stream) {
 	return launch<true>(h, d_rays, n, d_occluded, d_counts, (hipStream_t)stream);
+}
+
+int rtgi_hip_closest_hit_device_noalloc(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint32_t n, rtgi_hit *d_hits, void *stream) {
+	if (!h) return RTGI_ERR_INVALID;
+	if (h->device < 0) return fail(h, RTGI_ERR_DEVICE, "host-only handle: traversal needs a GPU");
+	if (n > NOALLOC_MAX_RAYS)
+		return fail(h, RTGI_ERR_INVALID, "closest_hit_device_noalloc takes at most " + std::to_string(NOALLOC_MAX_RAYS) + " rays per call");
+	if (n != 0 && (!d_rays || !d_hits)) return fail(h, RTGI_ERR_INVALID, "null ray or output buffer");
+	unsigned char *base = h->device < MAX_DEVICES ? g_scratch_ptr[h->device] : nullptr;  // set by rtgi_hip_create
+	if (!base) return fail(h, RTGI_ERR_DEVICE, "no fixed scratch memory on this GPU");
+	Scratch sc;
+	sc.counter = reinterpret_cast<uint32_t *>(base);
+	sc.sort = reinterpret_cast<uint32_t *>(base + NOALLOC_COUNTER_BYTES);
+	sc.sort_cap = NOALLOC_MAX_RAYS;
+	sc.sort_temp = base + NOALLOC_COUNTER_BYTES + NOALLOC_SORT_BYTES;
+	sc.sort_temp_bytes = NOALLOC_TEMP_BYTES;
+	sc.spill = reinterpret_cast<int32_t *>(base + NOALLOC_COUNTER_BYTES + NOALLOC_SORT_BYTES + NOALLOC_TEMP_BYTES);
+	sc.spill_words = NOALLOC_SPILL_BYTES / sizeof(int32_t);
+	const BatchView one{d_rays, n, false, d_hits};
+	return launch_batches(h, &one, 1, nullptr, (hipStream_t)stream, &sc);
 }
 
 void *rtgi_hip_host_alloc(size_t bytes) {

@@ -27,7 +27,7 @@ EXPORTS = [
     "rtgi_hip_incoherent_ray_cost",
     "rtgi_hip_get_nodes", "rtgi_hip_get_triangle_order", "rtgi_hip_closest_hit", "rtgi_hip_any_hit",
     "rtgi_hip_host_alloc", "rtgi_hip_host_free", "rtgi_hip_host_register", "rtgi_hip_host_unregister",
-    "rtgi_hip_closest_hit_device", "rtgi_hip_any_hit_device", "rtgi_hip_trace_batches_device", "rtgi_hip_camera_rays_device",
+    "rtgi_hip_closest_hit_device", "rtgi_hip_any_hit_device", "rtgi_hip_closest_hit_device_noalloc", "rtgi_hip_trace_batches_device", "rtgi_hip_camera_rays_device",
     "rtgi_hip_pixel_offsets_device", "rtgi_hip_shadow_rays_device", "rtgi_hip_bounce_rays_device", "rtgi_hip_set_shading",
     "rtgi_hip_shade_primary_device", "rtgi_hip_shade_local_device", "rtgi_hip_framebuffer_add_device",
     "rtgi_hip_framebuffer_rgb8_device", "rtgi_hip_profile_begin", "rtgi_hip_profile_end",
@@ -74,6 +74,7 @@ def lib():
         L.rtgi_hip_any_hit.argtypes = [vp, vp, u32, vp]
         L.rtgi_hip_closest_hit_device.argtypes = [vp, vp, u32, vp, vp, vp]
         L.rtgi_hip_any_hit_device.argtypes = [vp, vp, u32, vp, vp, vp]
+        L.rtgi_hip_closest_hit_device_noalloc.argtypes = [vp, vp, u32, vp, vp]
         L.rtgi_hip_host_alloc.argtypes = [sz]
         L.rtgi_hip_host_alloc.restype = vp
         L.rtgi_hip_host_free.argtypes = [vp]
@@ -206,6 +207,11 @@ class HipBvhTracer:
         self._check(lib().rtgi_hip_closest_hit_device(
             self._h, d_rays.data_ptr(), n, d_hits.data_ptr(), d_counts.data_ptr() if d_counts is not None else None,
             self._stream(stream)))
+
+    def closest_hit_device_noalloc(self, d_rays, d_hits, stream=None):
+        """closest_hit_device in the library's fixed scratch memory: allocates nothing, at most 2^21 rays."""
+        n = self._check_device_args(d_rays, d_hits, 4, None)
+        self._check(lib().rtgi_hip_closest_hit_device_noalloc(self._h, d_rays.data_ptr(), n, d_hits.data_ptr(), self._stream(stream)))
 
     def any_hit_device(self, d_rays, d_occluded, d_counts=None, stream=None):
         n = self._check_device_args(d_rays, d_occluded, 1, d_counts)
