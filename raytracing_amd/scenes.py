@@ -172,37 +172,55 @@ def cornell(n=1):
 
 def sponza_class(target_tris=262144, seed=0):
     """Atrium-like architectural scene (floor, walls, two colonnades with arches, hanging drapes) in
-    [-1500,1500] x [0,1200] x [-700,700], tessellated to about target_tris triangles."""
-    rs = np.random.RandomState(seed)
-    k = max(1, int(round(np.sqrt(target_tris / 262144.0) * 8)))
-    parts = [
-        _quad_grid([-1500, 0, -700], [3000, 0, 0], [0, 0, 1400], 24 * k, 12 * k,
-                   displace=lambda S, T: np.stack([0 * S, 4 * np.sin(40 * S) * np.sin(31 * T), 0 * S], -1)),
-        _quad_grid([-1500, 1200, -700], [0, 0, 1400], [3000, 0, 0], 6 * k, 12 * k),
-        _quad_grid([-1500, 0, -700], [0, 1200, 0], [3000, 0, 0], 8 * k, 20 * k),
-        _quad_grid([-1500, 0, 700], [3000, 0, 0], [0, 1200, 0], 20 * k, 8 * k),
-        _quad_grid([-1500, 0, -700], [0, 0, 1400], [0, 1200, 0], 10 * k, 8 * k),
-        _quad_grid([1500, 0, -700], [0, 1200, 0], [0, 0, 1400], 8 * k, 10 * k),
-    ]
-    for z in (-350.0, 350.0):
-        for i in range(12):
-            x = -1320.0 + i * 240.0
-            parts.append(_cylinder([x, 0, z], 38.0, 520.0, 6 * k, 6 * k))
-            parts.append(_box([x - 55, 520, z - 55], [x + 55, 560, z + 55], k))
-            if i < 11:  # arch between two columns
-                def arch(S, T, x=x, z=z):
-                    ang = np.pi * S
-                    return np.stack([x + 120 - 120 * np.cos(ang), 560 + 90 * np.sin(ang), z - 40 + 80 * T], -1)
-                parts.append(_quad_grid([0, 0, 0], [0, 0, 0], [0, 0, 0], 6 * k, 2 * k, displace=arch))
-        parts.append(_quad_grid([-1440, 650, z], [2880, 0, 0], [0, 200, 0], 24 * k, 2 * k))
-    for i in range(6):  # drapes
-        x = -1100.0 + i * 440.0
-        ph = rs.uniform(0, 6.28)
+    [-1500,1500] x [0,1200] x [-700,700], tessellated to target_tris triangles within a few percent (the
+    tessellation density is searched for the closest count)."""
+    def build(k, count_only):
+        g = lambda a: max(1, int(round(a * k)))  # noqa: E731
+        rs = np.random.RandomState(seed)
+        parts, count = [], [0]
 
-        def drape(S, T, ph=ph):
-            return np.stack([0 * S, 0 * S, 35 * np.sin(14 * S + ph) * (0.3 + T)], -1)
-        parts.append(_quad_grid([x, 980, -40], [260, 0, 0], [0, -620, 0], 16 * k, 16 * k, displace=drape))
-    return _finish(np.concatenate(parts, axis=0))
+        def grid(origin, du, dv, nu, nv, displace=None):
+            count[0] += 2 * nu * nv
+            if not count_only:
+                parts.append(_quad_grid(origin, du, dv, nu, nv, displace=displace))
+
+        grid([-1500, 0, -700], [3000, 0, 0], [0, 0, 1400], g(24), g(12),
+             displace=lambda S, T: np.stack([0 * S, 4 * np.sin(40 * S) * np.sin(31 * T), 0 * S], -1))
+        grid([-1500, 1200, -700], [0, 0, 1400], [3000, 0, 0], g(6), g(12))
+        grid([-1500, 0, -700], [0, 1200, 0], [3000, 0, 0], g(8), g(20))
+        grid([-1500, 0, 700], [3000, 0, 0], [0, 1200, 0], g(20), g(8))
+        grid([-1500, 0, -700], [0, 0, 1400], [0, 1200, 0], g(10), g(8))
+        grid([1500, 0, -700], [0, 1200, 0], [0, 0, 1400], g(8), g(10))
+        for z in (-350.0, 350.0):
+            for i in range(12):
+                x = -1320.0 + i * 240.0
+
+                def column(S, T, x=x, z=z):
+                    ang = 2 * np.pi * S
+                    return np.stack([x + 38.0 * np.cos(ang), 520.0 * T, z + 38.0 * np.sin(ang)], -1)
+                grid([0, 0, 0], [0, 0, 0], [0, 0, 0], g(6), g(6), displace=column)
+                lo, hi = np.array([x - 55, 520, z - 55]), np.array([x + 55, 560, z + 55])
+                ex, ey, ez = np.diag(hi - lo)
+                for o, du, dv in ((lo, ex, ey), (lo + ez, ey, ex), (lo, ey, ez), (lo + ex, ez, ey), (lo, ez, ex), (lo + ey, ex, ez)):
+                    grid(o, du, dv, g(1), g(1))
+                if i < 11:  # arch between two columns
+                    def arch(S, T, x=x, z=z):
+                        ang = np.pi * S
+                        return np.stack([x + 120 - 120 * np.cos(ang), 560 + 90 * np.sin(ang), z - 40 + 80 * T], -1)
+                    grid([0, 0, 0], [0, 0, 0], [0, 0, 0], g(6), g(2), displace=arch)
+            grid([-1440, 650, z], [2880, 0, 0], [0, 200, 0], g(24), g(2))
+        for i in range(6):  # drapes
+            x = -1100.0 + i * 440.0
+            ph = rs.uniform(0, 6.28)
+
+            def drape(S, T, ph=ph):
+                return np.stack([0 * S, 0 * S, 35 * np.sin(14 * S + ph) * (0.3 + T)], -1)
+            grid([x, 980, -40], [260, 0, 0], [0, -620, 0], g(16), g(16), displace=drape)
+        return count[0], parts
+
+    k0 = np.sqrt(target_tris / 7488.0)  # the counts above sum to 7488 k^2 before rounding
+    best_k = min((k0 * f for f in np.linspace(0.8, 1.25, 181)), key=lambda k: abs(build(k, True)[0] - target_tris))
+    return _finish(np.concatenate(build(best_k, False)[1], axis=0))
 
 
 def terrain_objects(target_tris=1 << 20, seed=3):
