@@ -33,7 +33,10 @@
 namespace rtgi_dev {
 
 constexpr int BLOCK = 256;      // 4 waves per workgroup
-constexpr int STACK_LDS = 24;   // pending nodes per lane held in LDS (beyond the one in a register)
+#ifndef RTGI_STACK_LDS
+#define RTGI_STACK_LDS 24
+#endif
+constexpr int STACK_LDS = RTGI_STACK_LDS;  // pending nodes per lane held in LDS (beyond the one in a register)
 constexpr int COUNTER_STRIDE = 32;
 #ifndef RTGI_TOP_NODES
 #define RTGI_TOP_NODES 256
