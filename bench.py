@@ -22,6 +22,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, vendor peak
+# What bounds the traversal is not HBM (nodes and triangles of the 2^20-triangle scene are 112 MiB: they live in the
+# 256 MiB Infinity Cache and mostly in the L2s) but the rate at which a CU's vector memory pipeline takes 16-byte
+# loads whose 64 lanes go to 64 different cache lines. scripts/ubench/gather_mix measures that rate with the
+# kernel's own access shape (dependent random 64-byte records, four loads each, 77 % of them L2 hits, three waves
+# per SIMD); bench.py runs it on the box when the binary is there, else it uses the figure measured for
+# profiles/r02_ubench_gather_mix_3waves.txt.
+LANE_LOADS_PER_S_FALLBACK = 4 * 213.2e9
+MISS_RECORDS_PER_S_FALLBACK = 71.6e9
+SIMDS, VALU_CYCLES_PER_INSTRUCTION = 1024, 4
 
 WORKLOADS = {
     # name: (scene generator, kwargs, camera position, direction, up)
@@ -94,17 +103,26 @@ def algorithmic_bytes(t, d_rays, layout):
     n = d_rays.shape[0]
     d_hits = torch.empty((n, 4), dtype=torch.float32, device=d_rays.device)
     d_cnt = torch.zeros((n, 2), dtype=torch.int32, device=d_rays.device)
+    t.profile_begin()
     t.closest_hit_device(d_rays, d_hits, d_cnt)
     torch.cuda.synchronize(d_rays.device)
+    work = t.profile_work()  # rays, inner pops, triangle tests, inner pops served from LDS
+    t.profile_end()
     s = d_cnt.sum(0, dtype=torch.int64).cpu().numpy()
+    assert work[0] == n and work[1] == int(s[0]) and work[2] == int(s[1])
     per_tri = 52 + (4 if layout == "indexed" else 0)
     total = 48 * n + 56 * int(s[0]) + per_tri * int(s[1])
     hit_rate = float((d_hits[:, 0] != float(np.finfo(np.float32).max)).float().mean().item())
-    return total, float(s[0]) / n, float(s[1]) / n, hit_rate
+    # 16-byte loads the lanes send to the vector cache: four per inner node not served from LDS, three per
+    # triangle, two per ray
+    lane_loads = 4 * (work[1] - work[3]) + 3 * work[2] + 2 * n
+    return dict(bytes=total, pops=float(s[0]) / n, tests=float(s[1]) / n, hit_rate=hit_rate, lane_loads=int(lane_loads),
+                lds_share=work[3] / max(work[1], 1), max_pops=int(d_cnt[:, 0].max().item()), hits=d_hits)
 
 
-def cpu_baseline(args, w):
-    """The CPU oracle (restated reference traversal, all host cores) on a bounded sample of the same rays."""
+def cpu_baseline(args, w, gpu_hits):
+    """The CPU oracle (restated reference traversal) on a bounded sample of the same rays: all host threads, then
+    one thread on a sixteenth of the batch. Also the checker: its hit records must be the GPU's."""
     from oracle import oracle as orc
     # the oracle permutes the triangle list itself for the flat layout: hand it the original order
     o = orc.Bbvh(w["pos"], w["tri_original"], layout=args.layout, **_oracle_split(args.bvh))
@@ -112,12 +130,85 @@ def cpu_baseline(args, w):
     o.closest_hit(rays[:20000])  # warm-up: thread pool, caches
     passes, dt, t0 = 0, 0.0, time.time()
     while dt < args.cpu_seconds:  # whole passes over the batch until the time budget is used
-        o.closest_hit(rays)
+        cpu_hits = o.closest_hit(rays)
         passes += 1
         dt = time.time() - t0
+    identical = bool(cpu_hits.tobytes() == gpu_hits.tobytes())
+    part = rays[::16]
+    t1 = time.time()
+    o.closest_hit(part, threads=1)
+    dt1 = time.time() - t1
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = [l.split(":", 1)[1].strip() for l in f if l.startswith("model name")][0]
+    except (OSError, IndexError):
+        pass
     return {"value": round(passes * len(rays) / dt / 1e6, 4), "unit": "Mrays/s", "cores": orc.max_threads(), "kind": "port",
-            "sample": "%d passes over the same %d bounce rays in %.1f s; CPU restatement of the reference tracer, "
-                      "OpenMP schedule(dynamic,1024), no per-ray stats timers" % (passes, len(rays), dt)}
+            "one_thread": round(len(part) / dt1 / 1e6, 4), "host_cpu": model, "host_logical_cpus": os.cpu_count(),
+            "hits_identical_to_gpu": identical,
+            "sample": "%d passes over the same %d bounce rays in %.1f s on %d threads, then every 16th ray on one thread in "
+                      "%.1f s; CPU restatement of the reference tracer, OpenMP schedule(dynamic,1024), no per-ray stats "
+                      "timers" % (passes, len(rays), dt, orc.max_threads(), dt1)}
+
+
+def host_buffer_rates(t, rays, d_hits):
+    """rtgi_hip_closest_hit on the same batch with rays and hits in host memory, PCIe both ways inside the call:
+    once with ordinary (pageable) numpy arrays, once with page-locked buffers from rtgi_hip_host_alloc."""
+    import ctypes
+    from raytracing_amd import tracer
+    n = len(rays)
+    want = d_hits.cpu().numpy().tobytes()
+    L = tracer.lib()
+
+    def rate(rays_ptr, hits_ptr, reps=5):
+        t._check(L.rtgi_hip_closest_hit(t._h, rays_ptr, n, hits_ptr))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            t._check(L.rtgi_hip_closest_hit(t._h, rays_ptr, n, hits_ptr))
+        return round(reps * n / (time.perf_counter() - t0) / 1e6, 2)
+
+    hits = np.zeros((n, 4), np.float32)
+    pageable = rate(rays.ctypes.data, hits.ctypes.data)
+    assert hits.tobytes() == want, "host-buffer path disagrees with the device path"
+    out = {"value": pageable, "unit": "Mrays/s",
+           "note": "rtgi_hip_closest_hit on the same batch from ordinary host memory, copies included; "
+                   "page_locked: the same with buffers from rtgi_hip_host_alloc"}
+    p_rays, p_hits = L.rtgi_hip_host_alloc(rays.nbytes), L.rtgi_hip_host_alloc(hits.nbytes)
+    if p_rays and p_hits:
+        ctypes.memmove(p_rays, rays.ctypes.data, rays.nbytes)
+        out["page_locked"] = rate(p_rays, p_hits)
+        got = ctypes.string_at(p_hits, hits.nbytes)
+        assert got == want, "host-buffer path (page-locked) disagrees with the device path"
+    for ptr in (p_rays, p_hits):
+        if ptr:
+            L.rtgi_hip_host_free(ptr)
+    return out
+
+
+def gather_ceiling():
+    """(16-byte lane loads per second, 64-byte L2-miss records per second, source) of this GPU, measured now by
+    scripts/ubench/gather_mix if it has been built, else the figures recorded under profiles/."""
+    import subprocess
+    exe = os.path.join(ROOT, "scripts", "ubench", "gather_mix")
+    if os.path.exists(exe):
+        try:
+            out = subprocess.run([exe, "3", "quick"], capture_output=True, text=True, timeout=60).stdout
+            vals = dict(line.split() for line in out.splitlines() if line.startswith(("LANE_LOADS", "MISS_RECORDS")))
+            return float(vals["LANE_LOADS_PER_S"]), float(vals["MISS_RECORDS_PER_S"]), "measured on this GPU by scripts/ubench/gather_mix"
+        except (OSError, KeyError, ValueError, subprocess.SubprocessError):
+            pass
+    return LANE_LOADS_PER_S_FALLBACK, MISS_RECORDS_PER_S_FALLBACK, "profiles/r02_ubench_gather_mix_3waves.txt"
+
+
+def kernel_source_hash():
+    """Identifies the kernel (traversal code and node layout) the counters under profiles/ were taken with."""
+    import hashlib
+    h = hashlib.sha1()
+    for name in ("trace_kernel.h", "bvh_host.cpp"):
+        with open(os.path.join(ROOT, "raytracing_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:12]
 
 
 def presort(rays, how):
@@ -186,7 +277,9 @@ def main():
     n = d_rays.shape[0]
     d_hits = torch.empty((n, 4), dtype=torch.float32, device=d_rays.device)
 
-    total_bytes, pops, tests, hit_rate = algorithmic_bytes(t, d_rays, args.layout)
+    alg = algorithmic_bytes(t, d_rays, args.layout)
+    total_bytes, pops, tests, hit_rate = alg["bytes"], alg["pops"], alg["tests"], alg["hit_rate"]
+    lane_rate, miss_rate, rate_source = gather_ceiling() if rank == 0 else (LANE_LOADS_PER_S_FALLBACK, MISS_RECORDS_PER_S_FALLBACK, "")
 
     def barrier():
         torch.cuda.synchronize(device)
@@ -205,6 +298,8 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_total_ms, launches = t.profile_end()
     kernel_ms = kernel_total_ms / max(launches, 1)
+    # the timed launches did the work: the last one's hit records are the counting launch's
+    assert torch.equal(d_hits, alg["hits"]), "timed launch and counting launch disagree"
 
     stats = torch.tensor([elapsed, float(n)], dtype=torch.float64, device="cuda:%d" % device if args.backend == "nccl" else "cpu")
     if world > 1:
@@ -244,45 +339,77 @@ def main():
                 "primary_hit_rate": round(w["primary_hit_rate"], 4),
                 "bvh_build_s": round(w["build_s"], 2),
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": _measured_traffic(args.workload),
-                "traffic_GBs": (round(_measured_traffic(args.workload) / (kernel_ms * 1e-3) / 1e9, 1)
-                                if _measured_traffic(args.workload) else None),
-                "kernel": "rtgi_dev::trace_kernel<closest_hit> (ray sort and counter reset excluded)",
-                "kernel_ms": round(kernel_ms, 4),
-                "algorithmic_bytes_per_launch": int(total_bytes),
-                "algorithmic_bytes_per_ray": round(total_bytes / n, 1),
-            },
+            "roofline": roofline(args.workload, total_bytes, n, kernel_ms, alg, lane_rate, miss_rate, rate_source),
         }
         # the drop-in form of the same call: rays and hits in host memory, PCIe both ways inside the call (never `value`)
         if not args.no_host_buffers:
-            t.closest_hit(w["bounce"])
-            t0 = time.perf_counter()
-            for _ in range(3):
-                t.closest_hit(w["bounce"])
-            out["host_buffer_path"] = {"value": round(3 * n / (time.perf_counter() - t0) / 1e6, 2), "unit": "Mrays/s",
-                                       "note": "rtgi_hip_closest_hit on the same batch from host memory, copies included"}
+            out["host_buffer_path"] = host_buffer_rates(t, w["bounce"], d_hits)
         if not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(args, w)
+            out["cpu_baseline"] = cpu_baseline(args, w, d_hits.cpu().numpy().view(np.dtype([("t", "<f4"), ("beta", "<f4"), ("gamma", "<f4"), ("ref", "<u4")])).reshape(-1))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def _measured_traffic(workload):
-    """HBM bytes per launch from the rocprofv3 PMC passes kept under profiles/ (null until measured)."""
+def roofline(workload, total_bytes, n, kernel_ms, alg, lane_rate, miss_rate, rate_source):
+    """The ceiling that binds the dominant kernel and how close the kernel is to it.
+
+    `achieved` is the reference's algorithmic bytes per launch over the kernel time. `peak` is the same bytes over
+    the shortest time any resource allows for this launch's work; `frac` = achieved / peak = that time / kernel time.
+    Resources, each with its demand per launch and its capacity:
+      lane loads   16-byte loads of lanes going to different lines (counted by the kernel itself) / measured rate
+      valu         vector instructions x 4 cycles on 1024 SIMDs (counters under profiles/, only for this kernel)
+      beyond L2    L2 misses (counters under profiles/) / measured rate of random 64-byte fetches that miss L2
+      hbm          bytes beyond L2 (counters under profiles/) / 8 TB/s
+      chain        the longest ray's inner-node visits x the latency of one dependent fetch
+    The counters under profiles/ are used only if they were taken with this kernel source (hash) and workload."""
+    t_kernel = kernel_ms * 1e-3
+    times = {"lane_loads": alg["lane_loads"] / lane_rate, "chain": alg["max_pops"] * 355e-9}
+    pmc = _measured_counters(workload)
+    if pmc:
+        times["valu"] = pmc["valu_instructions"] * VALU_CYCLES_PER_INSTRUCTION / SIMDS / (pmc["clock_ghz"] * 1e9)
+        times["beyond_l2"] = pmc["l2_misses"] / miss_rate
+        times["hbm"] = pmc["bytes_beyond_l2"] / (HBM_PEAK_GBS * 1e9)
+    bound = max(times, key=times.get)
+    names = {"lane_loads": "vector memory pipeline: 16-byte loads of lanes that go to different cache lines",
+             "valu": "vector instruction issue", "beyond_l2": "random 64-byte fetches that miss L2", "hbm": "hbm",
+             "chain": "latency of the longest ray's chain of dependent fetches"}
+    achieved = total_bytes / t_kernel / 1e9
+    frac = times[bound] / t_kernel
+    return {
+        "bound": names[bound],
+        "achieved": round(achieved, 1),
+        "peak": round(achieved / frac, 1),
+        "unit": "GB/s",
+        "frac": round(frac, 4),
+        "traffic": pmc["bytes_beyond_l2"] if pmc else None,
+        "kernel": "rtgi_dev::trace_kernel<closest_hit> (ray sort and counter reset excluded)",
+        "kernel_ms": round(kernel_ms, 4),
+        "algorithmic_bytes_per_launch": int(total_bytes),
+        "algorithmic_bytes_per_ray": round(total_bytes / n, 1),
+        "algorithmic_bytes_over_hbm_peak": round(achieved / HBM_PEAK_GBS, 4),
+        "floor_ms_by_resource": {k: round(v * 1e3, 4) for k, v in sorted(times.items())},
+        "lane_loads_per_launch": alg["lane_loads"],
+        "lane_load_rate_per_s": lane_rate,
+        "lane_load_rate_source": rate_source,
+        "inner_visits_served_from_lds": round(alg["lds_share"], 4),
+        "counters": ("profiles/traffic.json" if pmc else "none for kernel source %s: traffic, valu, beyond_l2 and hbm not priced" % kernel_source_hash()),
+    }
+
+
+def _measured_counters(workload):
+    """Per-launch hardware counters of the traversal kernel from the rocprofv3 PMC passes kept under profiles/
+    (scripts/pmc_bench.sh + scripts/pmc_to_traffic.py), or None if they belong to another kernel source."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(workload)
+            entry = json.load(f).get(workload)
     except (OSError, ValueError):
         return None
+    if not isinstance(entry, dict) or entry.get("kernel_source") != kernel_source_hash():
+        return None
+    return entry
 
 
 if __name__ == "__main__":

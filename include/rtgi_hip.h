@@ -119,7 +119,10 @@ int rtgi_hip_get_triangle_order(const rtgi_hip_tracer *h, uint32_t *out);
 /* wf::batch_ray_tracer::compute_closest_hit(), libgi/wavefront-rt.h:67-73, over n rays in host memory:
  * hits[i] = closest_hit(rays[i]) (bvh2.cpp:415-463). ref is the id the reference would return: an
  * index into the permuted triangle list for the flat layout, an original id for the indexed one.
- * Copies rays to the GPU, traces, copies hits back; synchronous. */
+ * Synchronous. Batches of more than 256 rays go through the GPU in chunks on three streams (rays of chunk k + 1 on
+ * their way up while chunk k is traced; the kernel stores hit records straight into page-locked host memory).
+ * Buffers in ordinary memory are staged through page-locked slots by a few copying threads; buffers from
+ * rtgi_hip_host_alloc / rtgi_hip_host_register are used in place. */
 int rtgi_hip_closest_hit(rtgi_hip_tracer *h, const rtgi_ray *rays, uint32_t n, rtgi_hit *hits);
 
 /* compute_any_hit(), wavefront-rt.h:74-80 / bvh2.cpp:465-501: occluded[i] = any_hit(rays[i]) as 0/1. */
@@ -243,6 +246,11 @@ int rtgi_hip_bounce_rays_device(rtgi_hip_tracer *h, const rtgi_ray *d_rays, cons
  * launches (at most 4096 are kept). Sorting and copies are not included. */
 int rtgi_hip_profile_begin(rtgi_hip_tracer *h);
 int rtgi_hip_profile_end(rtgi_hip_tracer *h, double *kernel_ms_total, uint32_t *launches);
+/* Work done by the counting launches (closest_hit / any_hit with d_counts) since the last profile_begin, summed
+ * over their rays: out[0] rays, out[1] inner nodes popped, out[2] triangles tested (what a COUNT_HITS build of the
+ * reference counts per ray, bvh.h:10, bvh2.cpp:422-461), out[3] the inner-node visits among out[1] that were served
+ * from the kernel's copy of the top of the tree in LDS instead of the vector cache. Waits for the GPU. */
+int rtgi_hip_profile_work(rtgi_hip_tracer *h, uint64_t out[4]);
 
 /* Text of the last error on this handle (h may be NULL: last error of a failed create). */
 const char *rtgi_hip_last_error(const rtgi_hip_tracer *h);

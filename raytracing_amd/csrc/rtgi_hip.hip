@@ -8,11 +8,14 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "bvh_host.h"
@@ -69,6 +72,85 @@ struct Scratch {
 
 }  // namespace
 
+// A few threads that copy memory in parallel: one thread moves ~10 GB/s, the staging copies of a host batch in
+// ordinary (pageable) memory need several times that to keep up with the PCIe link.
+class CopyPool {
+public:
+	~CopyPool() {
+		{
+			std::lock_guard<std::mutex> lock(guard);
+			quit = true;
+		}
+		wake.notify_all();
+		for (std::thread &t : workers) t.join();
+	}
+	// dst[0, bytes) = src[0, bytes), split over the workers and the calling thread; returns when it is done
+	void copy(void *dst, const void *src, size_t bytes) {
+		const size_t parts = workers.size() + 1;
+		if (bytes < (1u << 20) || parts == 1 || !started()) {
+			memcpy(dst, src, bytes);
+			return;
+		}
+		const size_t piece = ((bytes + parts - 1) / parts + 4095) & ~size_t(4095);
+		{
+			std::lock_guard<std::mutex> lock(guard);
+			job_dst = static_cast<char *>(dst), job_src = static_cast<const char *>(src), job_bytes = bytes, job_piece = piece;
+			pending = workers.size();
+			++generation;
+		}
+		wake.notify_all();
+		memcpy(dst, src, std::min(piece, bytes));  // piece 0 is the caller's
+		std::unique_lock<std::mutex> lock(guard);
+		done.wait(lock, [&] { return pending == 0; });
+	}
+
+private:
+	bool started() {
+		if (tried) return !workers.empty();
+		tried = true;
+		try {
+			for (unsigned i = 0; i < 3; ++i) workers.emplace_back([this, i] { run(i + 1); });
+		} catch (const std::system_error &) {  // no threads to be had: the caller copies alone
+		}
+		return !workers.empty();
+	}
+	void run(size_t part) {
+		uint64_t seen = 0;
+		for (;;) {
+			std::unique_lock<std::mutex> lock(guard);
+			wake.wait(lock, [&] { return quit || generation != seen; });
+			if (quit) return;
+			seen = generation;
+			char *dst = job_dst;
+			const char *src = job_src;
+			const size_t bytes = job_bytes, lo = std::min(bytes, part * job_piece), hi = std::min(bytes, lo + job_piece);
+			lock.unlock();
+			if (hi > lo) memcpy(dst + lo, src + lo, hi - lo);
+			lock.lock();
+			if (--pending == 0) done.notify_all();
+		}
+	}
+	std::vector<std::thread> workers;
+	std::mutex guard;
+	std::condition_variable wake, done;
+	char *job_dst = nullptr;
+	const char *job_src = nullptr;
+	size_t job_bytes = 0, job_piece = 0, pending = 0;
+	uint64_t generation = 0;
+	bool quit = false, tried = false;
+};
+
+// Host batches go through the GPU in chunks on three streams: while chunk k is traced, chunk k + 1 comes up and
+// the results of chunk k - 1 go down. Memory that is not page-locked is staged through page-locked slots.
+struct HostPipe {
+	static constexpr int SLOTS = 3;
+	hipStream_t up = nullptr, run = nullptr, down = nullptr;
+	hipEvent_t came_up[SLOTS] = {}, traced[SLOTS] = {}, went_down[SLOTS] = {};
+	void *slot_rays[SLOTS] = {}, *slot_out[SLOTS] = {};
+	size_t slot_rays_cap = 0;  // rays per slot
+	CopyPool pool;
+};
+
 struct rtgi_hip_tracer {
 	int device = 0;  // -1: host-only handle (builds and inspects trees, cannot trace)
 	rtgi::BuildConfig cfg;
@@ -90,7 +172,8 @@ struct rtgi_hip_tracer {
 	uint32_t *d_block_counts = nullptr;
 	size_t block_counts_cap = 0;
 
-	// per-launch kernel timing (profile_begin / profile_end)
+	// per-launch kernel timing (profile_begin / profile_end) and the work sums of counting launches
+	unsigned long long *d_totals = nullptr;
 	bool profiling = false;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
 	size_t events_used = 0;
@@ -124,6 +207,9 @@ struct rtgi_hip_tracer {
 	size_t stage_rays_cap = 0, stage_out_cap = 0;
 	// small host batches (the per-ray interface): pinned host memory that the kernel reads and writes directly
 	void *pinned = nullptr, *d_pinned = nullptr;
+	HostPipe *pipe = nullptr;
+	uint32_t host_chunk = 768u << 10;  // rays per chunk of a large host batch (every chunk's launch ends in its own tail)
+	bool host_direct = true;           // closest_hit on host batches: the kernel writes the hit records to host memory itself
 };
 
 namespace {
@@ -187,6 +273,8 @@ void read_tunables(rtgi_hip_tracer *h) {
 	h->n_segments = number("RTGI_HIP_SEGMENTS", 1, 8, 8) == 1 ? 1u : 8u;
 	h->top_in_lds = number("RTGI_HIP_TOP_IN_LDS", 0, 1, 1) != 0;
 	h->reorder = number("RTGI_HIP_REORDER", 0, 2, h->reorder);
+	h->host_chunk = (uint32_t)number("RTGI_HIP_HOST_CHUNK", 1 << 16, 1 << 30, (int)h->host_chunk);
+	h->host_direct = number("RTGI_HIP_HOST_DIRECT", 0, 1, 1) != 0;
 }
 
 int upload(rtgi_hip_tracer *h, const rtgi::SceneView &scene) {
@@ -471,6 +559,7 @@ int launch_batches(rtgi_hip_tracer *h, const BatchView *given, uint32_t n_given,
 		a.occluded = mode == 1 ? (uint8_t *)batches[0].out : nullptr;
 	}
 	a.counts = d_counts;
+	a.totals = (!fixed && h->profiling && d_counts) ? h->d_totals : nullptr;
 	a.spill = sc.spill;
 	a.ray_counter = sc.counter;
 	a.n_rays = n;
@@ -575,6 +664,51 @@ int ensure_stage(rtgi_hip_tracer *h, size_t ray_bytes, size_t out_bytes) {
 	return RTGI_OK;
 }
 
+// Streams and events of the host-batch pipeline, created on first use.
+int ensure_pipe(rtgi_hip_tracer *h) {
+	if (h->pipe) return RTGI_OK;
+	HostPipe *p = new (std::nothrow) HostPipe;
+	if (!p) return fail(h, RTGI_ERR_NOMEM, "out of host memory");
+	h->pipe = p;  // (destroy releases whatever part of it exists)
+	HIP_TRY(h, hipStreamCreateWithFlags(&p->up, hipStreamNonBlocking));
+	HIP_TRY(h, hipStreamCreateWithFlags(&p->run, hipStreamNonBlocking));
+	HIP_TRY(h, hipStreamCreateWithFlags(&p->down, hipStreamNonBlocking));
+	for (int i = 0; i < HostPipe::SLOTS; ++i) {
+		HIP_TRY(h, hipEventCreateWithFlags(&p->came_up[i], hipEventDisableTiming));
+		HIP_TRY(h, hipEventCreateWithFlags(&p->traced[i], hipEventDisableTiming));
+		HIP_TRY(h, hipEventCreateWithFlags(&p->went_down[i], hipEventDisableTiming));
+	}
+	return RTGI_OK;
+}
+
+// Page-locked staging slots for `chunk` rays and their results each.
+int ensure_slots(rtgi_hip_tracer *h, uint32_t chunk) {
+	HostPipe &p = *h->pipe;
+	if (chunk <= p.slot_rays_cap) return RTGI_OK;
+	for (int i = 0; i < HostPipe::SLOTS; ++i) {
+		if (p.slot_rays[i]) (void)hipHostFree(p.slot_rays[i]);
+		if (p.slot_out[i]) (void)hipHostFree(p.slot_out[i]);
+		p.slot_rays[i] = p.slot_out[i] = nullptr;
+	}
+	p.slot_rays_cap = 0;
+	for (int i = 0; i < HostPipe::SLOTS; ++i) {
+		HIP_TRY(h, hipHostMalloc(&p.slot_rays[i], (size_t)chunk * sizeof(rtgi_ray), hipHostMallocDefault));
+		HIP_TRY(h, hipHostMalloc(&p.slot_out[i], (size_t)chunk * sizeof(rtgi_hit), hipHostMallocDefault));
+	}
+	p.slot_rays_cap = chunk;
+	return RTGI_OK;
+}
+
+// Whether the copy engines can reach this host memory directly (rtgi_hip_host_alloc / rtgi_hip_host_register).
+bool is_page_locked(const void *ptr) {
+	hipPointerAttribute_t attr;
+	if (hipPointerGetAttributes(&attr, ptr) != hipSuccess) {
+		(void)hipGetLastError();  // ordinary memory is unknown to the runtime: not an error of this call
+		return false;
+	}
+	return attr.type == hipMemoryTypeHost;
+}
+
 template <bool ANY>
 int trace_host(rtgi_hip_tracer *h, const rtgi_ray *rays, uint32_t n, void *out) {
 	if (!h) return RTGI_ERR_INVALID;
@@ -601,10 +735,70 @@ int trace_host(rtgi_hip_tracer *h, const rtgi_ray *rays, uint32_t n, void *out) 
 	}
 	int rc = ensure_stage(h, (size_t)n * sizeof(rtgi_ray), out_bytes);
 	if (rc) return rc;
-	HIP_TRY(h, hipMemcpy(h->d_stage_rays, rays, (size_t)n * sizeof(rtgi_ray), hipMemcpyHostToDevice));
-	rc = launch<ANY>(h, (const rtgi_ray *)h->d_stage_rays, n, h->d_stage_out, nullptr, nullptr);
+	rc = ensure_pipe(h);
 	if (rc) return rc;
-	HIP_TRY(h, hipMemcpy(out, h->d_stage_out, out_bytes, hipMemcpyDeviceToHost));
+	HostPipe &p = *h->pipe;
+	// chunks of equal size, at most host_chunk rays each; a batch that fits one chunk still gains the parallel staging
+	const uint32_t n_chunks = (n + h->host_chunk - 1) / h->host_chunk;
+	const uint32_t chunk = ((n + n_chunks - 1) / n_chunks + 63u) & ~63u;
+	const size_t out_item = ANY ? 1 : sizeof(rtgi_hit);
+	const bool rays_locked = is_page_locked(rays), out_locked = is_page_locked(out);
+	if (!rays_locked || !out_locked) {
+		rc = ensure_slots(h, chunk);
+		if (rc) return rc;
+	}
+	auto first_of = [&](uint32_t k) { return (size_t)k * chunk; };
+	auto count_of = [&](uint32_t k) { return (uint32_t)std::min<size_t>(chunk, n - first_of(k)); };
+	// results of chunk k, once they have come down into its slot, go to the caller's buffer
+	auto hand_over = [&](uint32_t k) -> int {
+		HIP_TRY(h, hipEventSynchronize(p.went_down[k % HostPipe::SLOTS]));
+		if (!out_locked) p.pool.copy((char *)out + first_of(k) * out_item, p.slot_out[k % HostPipe::SLOTS], count_of(k) * out_item);
+		return RTGI_OK;
+	};
+	// work that earlier calls left on the default stream (the usual place for this handle's launches) comes first
+	HIP_TRY(h, hipStreamSynchronize(nullptr));
+	for (uint32_t k = 0; k < n_chunks; ++k) {
+		const int slot = (int)(k % HostPipe::SLOTS);
+		const size_t first = first_of(k);
+		const uint32_t count = count_of(k);
+		// the slot's previous user was chunk k - SLOTS: its rays have gone up and its results have been handed over
+		if (k >= (uint32_t)HostPipe::SLOTS) {
+			if (!rays_locked) HIP_TRY(h, hipEventSynchronize(p.came_up[slot]));
+			if ((rc = hand_over(k - HostPipe::SLOTS)) != RTGI_OK) return rc;
+		}
+		const rtgi_ray *src = rays + first;
+		if (!rays_locked) {
+			p.pool.copy(p.slot_rays[slot], src, (size_t)count * sizeof(rtgi_ray));
+			src = (const rtgi_ray *)p.slot_rays[slot];
+		}
+		rtgi_ray *d_rays = (rtgi_ray *)h->d_stage_rays + first;
+		char *d_out = (char *)h->d_stage_out + first * out_item;
+		// Hit records need no copy down: the kernel stores them (16 bytes each, once per ray) straight into the
+		// page-locked destination, which the stores reach over PCIe while the traversal goes on. (any_hit's single
+		// bytes would make as many PCIe writes for a sixteenth of the data: they come down as one copy.)
+		bool direct = !ANY && h->host_direct;
+		if (direct) {
+			void *host = out_locked ? (void *)((char *)out + first * out_item) : p.slot_out[slot], *dev = nullptr;
+			if (hipHostGetDevicePointer(&dev, host, 0) == hipSuccess && dev)
+				d_out = (char *)dev;
+			else {
+				(void)hipGetLastError();
+				direct = false;
+			}
+		}
+		HIP_TRY(h, hipMemcpyAsync(d_rays, src, (size_t)count * sizeof(rtgi_ray), hipMemcpyHostToDevice, p.up));
+		HIP_TRY(h, hipEventRecord(p.came_up[slot], p.up));
+		HIP_TRY(h, hipStreamWaitEvent(p.run, p.came_up[slot], 0));
+		rc = launch<ANY>(h, d_rays, count, d_out, nullptr, p.run);
+		if (rc) return rc;
+		HIP_TRY(h, hipEventRecord(p.traced[slot], p.run));
+		HIP_TRY(h, hipStreamWaitEvent(p.down, p.traced[slot], 0));
+		void *dst = out_locked ? (void *)((char *)out + first * out_item) : p.slot_out[slot];
+		if (!direct) HIP_TRY(h, hipMemcpyAsync(dst, d_out, (size_t)count * out_item, hipMemcpyDeviceToHost, p.down));
+		HIP_TRY(h, hipEventRecord(p.went_down[slot], p.down));
+	}
+	for (uint32_t k = n_chunks > (uint32_t)HostPipe::SLOTS ? n_chunks - HostPipe::SLOTS : 0; k < n_chunks; ++k)
+		if ((rc = hand_over(k)) != RTGI_OK) return rc;
 	return RTGI_OK;
 }
 
@@ -697,11 +891,25 @@ void rtgi_hip_destroy(rtgi_hip_tracer *h) {
 	DeviceScope device_scope(h->device);
 	free_device_tree(h);
 	if (h->d_counter) (void)hipFree(h->d_counter);
+	if (h->d_totals) (void)hipFree(h->d_totals);
 	if (h->d_stage_rays) (void)hipFree(h->d_stage_rays);
 	if (h->d_stage_out) (void)hipFree(h->d_stage_out);
 	if (h->d_block_counts) (void)hipFree(h->d_block_counts);
 	if (h->scratch_free) (void)hipEventDestroy(h->scratch_free);
 	if (h->pinned) (void)hipHostFree(h->pinned);
+	if (HostPipe *p = h->pipe) {
+		for (int i = 0; i < HostPipe::SLOTS; ++i) {
+			if (p->slot_rays[i]) (void)hipHostFree(p->slot_rays[i]);
+			if (p->slot_out[i]) (void)hipHostFree(p->slot_out[i]);
+			if (p->came_up[i]) (void)hipEventDestroy(p->came_up[i]);
+			if (p->traced[i]) (void)hipEventDestroy(p->traced[i]);
+			if (p->went_down[i]) (void)hipEventDestroy(p->went_down[i]);
+		}
+		if (p->up) (void)hipStreamDestroy(p->up);
+		if (p->run) (void)hipStreamDestroy(p->run);
+		if (p->down) (void)hipStreamDestroy(p->down);
+		delete p;
+	}
 	if (h->d_sort) (void)hipFree(h->d_sort);
 	if (h->d_sort_temp) (void)hipFree(h->d_sort_temp);
 	for (auto &e : h->events) {
@@ -1176,8 +1384,25 @@ int rtgi_hip_bounce_rays_device(rtgi_hip_tracer *h, const rtgi_ray *d_rays, cons
 int rtgi_hip_profile_begin(rtgi_hip_tracer *h) {
 	if (!h) return RTGI_ERR_INVALID;
 	if (h->device < 0) return fail(h, RTGI_ERR_DEVICE, "host-only handle: needs a GPU");
+	DeviceScope device_scope(h->device);
+	HIP_TRY(h, device_scope.status);
+	if (!h->d_totals) HIP_TRY(h, hipMalloc((void **)&h->d_totals, 4 * sizeof(unsigned long long)));
+	HIP_TRY(h, hipMemset(h->d_totals, 0, 4 * sizeof(unsigned long long)));
 	h->profiling = true;
 	h->events_used = 0;
+	return RTGI_OK;
+}
+
+int rtgi_hip_profile_work(rtgi_hip_tracer *h, uint64_t out[4]) {
+	if (!h || !out) return RTGI_ERR_INVALID;
+	if (h->device < 0) return fail(h, RTGI_ERR_DEVICE, "host-only handle: needs a GPU");
+	if (!h->d_totals) return fail(h, RTGI_ERR_INVALID, "profile_work: call profile_begin first");
+	DeviceScope device_scope(h->device);
+	HIP_TRY(h, device_scope.status);
+	HIP_TRY(h, hipDeviceSynchronize());
+	unsigned long long v[4];
+	HIP_TRY(h, hipMemcpy(v, h->d_totals, sizeof(v), hipMemcpyDeviceToHost));
+	for (int k = 0; k < 4; ++k) out[k] = v[k];
 	return RTGI_OK;
 }
 

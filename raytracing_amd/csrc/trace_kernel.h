@@ -57,6 +57,7 @@ struct TraceArgs {
 	float4 *hits;           // closest_hit output
 	uint8_t *occluded;      // any_hit output
 	uint32_t *counts;       // optional: 2 per ray
+	unsigned long long *totals;  // optional, counting kernels only: sums over the launch, see finish()
 	int32_t *spill;         // DEEP only: [level - STACK_LDS][global lane]
 	uint32_t *ray_counter;  // n_segments counters, COUNTER_STRIDE words apart (one cache line each)
 	uint32_t n_rays;
@@ -143,7 +144,8 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 	bool any_lane = MODE == 1;  // this lane's ray only asks whether anything is hit
 	const float4 *my_rays = a.rays;
 	void *my_out = nullptr;     // MIXED: where this lane's result goes
-	uint32_t n_inner = 0, n_tri = 0;
+	uint32_t n_inner = 0, n_tri = 0, n_top = 0;
+	unsigned long long sum_rays = 0, sum_inner = 0, sum_tri = 0, sum_top = 0;  // COUNT: over all rays of this lane
 	int32_t cur = IDLE;
 	int sp = 0;          // pending entries in memory (the next node to visit is `cur`, in a register)
 	bool plain = true;   // no NaN can arise in this ray's slab tests
@@ -179,6 +181,7 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 		if (COUNT) {
 			a.counts[2 * (size_t)ray_id] = n_inner;
 			a.counts[2 * (size_t)ray_id + 1] = n_tri;
+			sum_rays += 1, sum_inner += n_inner, sum_tri += n_tri, sum_top += n_top;
 		}
 		cur = IDLE;
 	};
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 				lim0 = next_up(t_max);
 				ray_id = local;
 				best_t = FLT_MAX, best_b = 0.0f, best_g = 0.0f, best_ref = 0;
-				n_inner = n_tri = 0;
+				n_inner = n_tri = n_top = 0;
 				cur = a.root_ref;
 				sp = 0;
 				lim = any_lane ? lim0 : __builtin_fminf(best_t, lim0);
@@ -285,6 +288,7 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 					u32x4 q0, q1, q2, q3;
 					if (cur < top_nodes) {
 						q0 = s_top[0][cur], q1 = s_top[1][cur], q2 = s_top[2][cur], q3 = s_top[3][cur];
+						if (COUNT) ++n_top;
 					} else {
 						q0 = __builtin_amdgcn_raw_buffer_load_b128(node_rsrc, voff, 0, 0);
 						q1 = __builtin_amdgcn_raw_buffer_load_b128(node_rsrc, voff + 16, 0, 0);
@@ -393,6 +397,13 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 				finish();
 			else
 				advance();
+		}
+	}
+	if (COUNT && a.totals) {  // rays, inner nodes popped, triangles tested, inner nodes read from the copy in LDS
+		unsigned long long v[4] = {sum_rays, sum_inner, sum_tri, sum_top};
+		for (int k = 0; k < 4; ++k) {
+			for (int step = 32; step > 0; step >>= 1) v[k] += __shfl_xor(v[k], step);
+			if (lane == 0) atomicAdd(a.totals + k, v[k]);
 		}
 	}
 #ifdef RTGI_DIAG

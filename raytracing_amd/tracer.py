@@ -30,7 +30,7 @@ EXPORTS = [
     "rtgi_hip_closest_hit_device", "rtgi_hip_any_hit_device", "rtgi_hip_closest_hit_device_noalloc", "rtgi_hip_trace_batches_device", "rtgi_hip_camera_rays_device",
     "rtgi_hip_pixel_offsets_device", "rtgi_hip_shadow_rays_device", "rtgi_hip_bounce_rays_device", "rtgi_hip_set_shading",
     "rtgi_hip_shade_primary_device", "rtgi_hip_shade_local_device", "rtgi_hip_framebuffer_add_device",
-    "rtgi_hip_framebuffer_rgb8_device", "rtgi_hip_profile_begin", "rtgi_hip_profile_end",
+    "rtgi_hip_framebuffer_rgb8_device", "rtgi_hip_profile_begin", "rtgi_hip_profile_end", "rtgi_hip_profile_work",
     "rtgi_hip_last_error",
 ]
 
@@ -93,6 +93,7 @@ def lib():
         L.rtgi_hip_framebuffer_rgb8_device.argtypes = [vp, vp, u32, u32, vp, vp]
         L.rtgi_hip_profile_begin.argtypes = [vp]
         L.rtgi_hip_profile_end.argtypes = [vp, vp, vp]
+        L.rtgi_hip_profile_work.argtypes = [vp, vp]
         L.rtgi_hip_last_error.argtypes = [vp]
         L.rtgi_hip_last_error.restype = cp
         _lib = L
@@ -329,6 +330,13 @@ class HipBvhTracer:
         ms, n = C.c_double(0.0), C.c_uint32(0)
         self._check(lib().rtgi_hip_profile_end(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def profile_work(self):
+        """(rays, inner nodes popped, triangles tested, inner-node visits served from LDS) summed over the counting
+        launches since profile_begin."""
+        out = (C.c_uint64 * 4)()
+        self._check(lib().rtgi_hip_profile_work(self._h, out))
+        return tuple(int(v) for v in out)
 
     def _check_device_args(self, d_rays, d_out, out_width, d_counts):
         import torch

@@ -3,10 +3,13 @@
 //  * do the L2-hit and the L2-miss share of a mixed gather add (one pipe) or overlap (two resources)?
 //    compare the measured time with  n (p / R_hit + (1 - p) / R_miss)  and with  n max(p / R_hit, (1 - p) / R_miss);
 //  * what does a record of half / a quarter of the bytes buy at each hit ratio?
-// Usage: gather_mix [waves_per_simd=3]
+// Usage: gather_mix [waves_per_simd=3] [quick]
+// quick: only the 64-byte / 4-load form at hit shares 0.77 and 0, one line each for bench.py to read:
+//   LANE_LOADS_PER_S <16-byte lane loads per second at 77 % L2 hits>   MISS_RECORDS_PER_S <64-byte records per second, no L2 hits>
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
@@ -52,6 +55,25 @@ int main(int argc, char **argv) {
 	CHECK(hipEventCreate(&e1));
 	const unsigned p_list[] = {0, 256, 512, 788, 922, 1024};  // share of fetches that go to the hot region, in 1/1024
 	const unsigned hot_bytes = 1u << 20;                        // 1 MiB: stays in each XCD's 4 MiB L2
+	if (argc > 2 && std::string(argv[2]) == "quick") {
+		double rate[2];
+		const unsigned p_quick[2] = {788, 0};
+		for (int k = 0; k < 2; ++k) {
+			float best = 1e30f;
+			for (int rep = 0; rep < 3; ++rep) {
+				CHECK(hipEventRecord(e0));
+				hipLaunchKernelGGL((gather<4, 6>), dim3(blocks), dim3(256), 0, 0, table, max_bytes, max_bytes >> 6, hot_bytes >> 6, p_quick[k], iters, out);
+				CHECK(hipEventRecord(e1));
+				CHECK(hipEventSynchronize(e1));
+				float ms;
+				CHECK(hipEventElapsedTime(&ms, e0, e1));
+				if (ms < best) best = ms;
+			}
+			rate[k] = (double)blocks * 256 * iters / (best * 1e-3);
+		}
+		printf("LANE_LOADS_PER_S %.4g\nMISS_RECORDS_PER_S %.4g\n", 4 * rate[0], rate[1]);
+		return 0;
+	}
 	printf("waves per SIMD %d; hot region %u KiB, table %u MiB\n", waves_per_simd, hot_bytes >> 10, max_bytes >> 20);
 	for (int variant = 0; variant < 4; ++variant) {
 		// 0: 64-byte records, 4 loads; 1: 64-byte stride, 2 loads; 2: 32-byte records packed, 2 loads; 3: 64-byte stride, 1 load
