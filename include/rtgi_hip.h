@@ -195,6 +195,14 @@ int rtgi_hip_camera_rays_device(rtgi_hip_tracer *h, const rtgi_camera *cam, cons
  * rtgi_hip_camera_rays_device. d_offsets: n pairs of floats. Needs no build(). */
 int rtgi_hip_pixel_offsets_device(rtgi_hip_tracer *h, uint32_t n, uint32_t sample, uint32_t seed, float *d_offsets, void *stream);
 
+/* The same two for a part of the frame (one GPU's tiles of a frame that several GPUs share): ray i and offset i
+ * belong to pixel d_pixels[i] = y * w + x of the camera's image, n of them, each below w * h. A pixel's offsets and
+ * its ray are those of the whole-frame calls, whichever part of the frame it is traced in. */
+int rtgi_hip_pixel_offsets_pixels_device(rtgi_hip_tracer *h, const uint32_t *d_pixels, uint32_t n, uint32_t sample, uint32_t seed,
+                                         float *d_offsets, void *stream);
+int rtgi_hip_camera_rays_pixels_device(rtgi_hip_tracer *h, const rtgi_camera *cam, const uint32_t *d_pixels, uint32_t n,
+                                       const float *d_offsets, rtgi_ray *d_rays, void *stream);
+
 /* Shadow rays of local_illumination::sample_pixel, gi/primary-hit.cpp:43-50, one slot per hit record: origin
  * diff_geom::x (libgi/rt.cpp:9), direction towards light_pos, t_max = distance - 1e-4 (ray::length_exclusive).
  * Slots whose hit record is a miss get an empty ray (t_max < t_min), which any_hit reports as not occluded. */
@@ -226,6 +234,16 @@ int rtgi_hip_shade_local_device(rtgi_hip_tracer *h, const rtgi_hit *d_hits, cons
  * (running mean rgb, sample count in w), zero-filled by the caller like framebuffer::clear. */
 int rtgi_hip_framebuffer_add_device(rtgi_hip_tracer *h, float *d_framebuffer, const float *d_radiance, uint32_t n, void *stream);
 
+/* Combining the framebuffers of several GPUs (no counterpart in the reference, which renders in one process). A
+ * framebuffer entry is a running mean with its sample count in w (libgi/framebuffer.cpp:10-18), so parts are
+ * combined as sums and counts. scatter: d_full[d_pixels[i]] = d_part[i], a GPU's densely stored pixels into their
+ * places in a frame-sized buffer (zero elsewhere). sums: in place, (mean, count) -> (mean * count, count) if to_sums,
+ * else back (pixels without samples stay zero). accumulate: d_dst[i] += d_src[i] on all four components. */
+int rtgi_hip_framebuffer_scatter_device(rtgi_hip_tracer *h, const float *d_part, const uint32_t *d_pixels, uint32_t n, float *d_full,
+                                        void *stream);
+int rtgi_hip_framebuffer_sums_device(rtgi_hip_tracer *h, float *d_framebuffer, uint32_t n, int to_sums, void *stream);
+int rtgi_hip_framebuffer_accumulate_device(rtgi_hip_tracer *h, float *d_dst, const float *d_src, uint32_t n, void *stream);
+
 /* framebuffer::png, libgi/framebuffer.cpp:21-30, without the file: 8-bit rgb, clamped, gamma 1/2.2, rows
  * flipped. d_rgb: 3 * w * h bytes. */
 int rtgi_hip_framebuffer_rgb8_device(rtgi_hip_tracer *h, const float *d_framebuffer, uint32_t w, uint32_t height,
@@ -239,6 +257,30 @@ int rtgi_hip_framebuffer_rgb8_device(rtgi_hip_tracer *h, const float *d_framebuf
 int rtgi_hip_bounce_rays_device(rtgi_hip_tracer *h, const rtgi_ray *d_rays, const rtgi_hit *d_hits, uint32_t n,
                                 uint32_t seed, uint32_t bounce, rtgi_ray *d_out, uint32_t *d_parent, uint32_t *d_count,
                                 void *stream);
+
+/* Paths of several segments (no counterpart in the reference, whose algorithms stop at the first hit; used by the
+ * frame loop of rtgi_hip_frame.h for "algo path"). A ray of a later segment carries its path's throughput (the
+ * product of the albedos met so far: cosine-weighted sampling of a lambertian surface weighs by the albedo) and
+ * the slot of the pixel sample it belongs to. All buffers: float4 / uint32 per ray.
+ * begin: for the n camera rays of a sample, throughput = 1, slot = i, radiance = 0.
+ * add: radiance[slot[j]] += throughput[j] * direct[j] for the m rays of a segment (direct = what
+ *   rtgi_hip_shade_local_device returned for them).
+ * extend: for the m rays that rtgi_hip_bounce_rays_device made (ray j continues ray d_parent[j]):
+ *   throughput_out[j] = throughput_in[parent] * albedo[parent], slot_out[j] = slot_in[parent]
+ *   (albedo = what rtgi_hip_shade_primary_device returned for the parent rays' hits). */
+int rtgi_hip_path_begin_device(rtgi_hip_tracer *h, uint32_t n, float *d_throughput, uint32_t *d_slot, float *d_radiance, void *stream);
+int rtgi_hip_path_add_device(rtgi_hip_tracer *h, const float *d_direct, const float *d_throughput, const uint32_t *d_slot, uint32_t m,
+                             float *d_radiance, void *stream);
+int rtgi_hip_path_extend_device(rtgi_hip_tracer *h, const float *d_albedo, const uint32_t *d_parent, uint32_t m,
+                                const float *d_throughput_in, const uint32_t *d_slot_in, float *d_throughput_out, uint32_t *d_slot_out,
+                                void *stream);
+
+/* rtgi_hip_bounce_rays_device with the random numbers of ray i keyed by d_keys[i] (or, with a table, by
+ * d_key_table[d_keys[i]]) instead of by i: keyed by its pixel, a path draws the same numbers however the frame's
+ * rays are split into batches or over GPUs. Either pointer may be NULL. */
+int rtgi_hip_bounce_rays_keyed_device(rtgi_hip_tracer *h, const rtgi_ray *d_rays, const rtgi_hit *d_hits, uint32_t n,
+                                      const uint32_t *d_keys, const uint32_t *d_key_table, uint32_t seed, uint32_t bounce,
+                                      rtgi_ray *d_out, uint32_t *d_parent, uint32_t *d_count, void *stream);
 
 /* Timing of the traversal kernel alone (what the reference's time_this_block(closest_hit), bvh2.cpp:417,
  * measures per call, here per launch): after profile_begin every closest_hit / any_hit launch is bracketed by

@@ -1154,8 +1154,24 @@ int rtgi_hip_trace_batches_device(rtgi_hip_tracer *h, const rtgi_batch *batches,
 	return launch_batches(h, views, n_batches, nullptr, (hipStream_t)stream);
 }
 
+namespace {
+int camera_rays(rtgi_hip_tracer *h, const rtgi_camera *cam, const uint32_t *d_pixels, uint32_t n_pixels, const float *d_offsets,
+                rtgi_ray *d_rays, void *stream);
+}
 int rtgi_hip_camera_rays_device(rtgi_hip_tracer *h, const rtgi_camera *cam, const float *d_offsets, rtgi_ray *d_rays,
                                 void *stream) {
+	return camera_rays(h, cam, nullptr, 0, d_offsets, d_rays, stream);
+}
+int rtgi_hip_camera_rays_pixels_device(rtgi_hip_tracer *h, const rtgi_camera *cam, const uint32_t *d_pixels, uint32_t n,
+                                       const float *d_offsets, rtgi_ray *d_rays, void *stream) {
+	if (!h) return RTGI_ERR_INVALID;
+	if (n == 0) return RTGI_OK;
+	if (!d_pixels) return fail(h, RTGI_ERR_INVALID, "camera_rays_pixels: null pixel list");
+	return camera_rays(h, cam, d_pixels, n, d_offsets, d_rays, stream);
+}
+namespace {
+int camera_rays(rtgi_hip_tracer *h, const rtgi_camera *cam, const uint32_t *d_pixels, uint32_t n_pixels, const float *d_offsets,
+                rtgi_ray *d_rays, void *stream) {
 	if (!h || !cam) return RTGI_ERR_INVALID;
 	if (h->device < 0) return fail(h, RTGI_ERR_DEVICE, "host-only handle: needs a GPU");
 	if (cam->w <= 0 || cam->h <= 0 || !d_rays || (reinterpret_cast<uintptr_t>(d_rays) & 15u))
@@ -1175,21 +1191,128 @@ int rtgi_hip_camera_rays_device(rtgi_hip_tracer *h, const rtgi_camera *cam, cons
 	a.w = cam->w, a.h = cam->h;
 	a.offsets = (const float2 *)d_offsets;
 	a.rays = (float4 *)d_rays;
-	const uint32_t n = (uint32_t)cam->w * (uint32_t)cam->h;
+	const uint32_t n = d_pixels ? n_pixels : (uint32_t)cam->w * (uint32_t)cam->h;
+	a.pixels = d_pixels;  // (the caller vouches for pixels[i] < w * h: they only enter arithmetic, no address)
+	a.n = n;
 	hipLaunchKernelGGL(rtgi_dev::camera_rays_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
 	HIP_TRY(h, hipGetLastError());
 	return RTGI_OK;
 }
+}  // namespace
 
+namespace {
+int pixel_offsets(rtgi_hip_tracer *h, const uint32_t *d_pixels, uint32_t n, uint32_t sample, uint32_t seed, float *d_offsets, void *stream);
+}
 int rtgi_hip_pixel_offsets_device(rtgi_hip_tracer *h, uint32_t n, uint32_t sample, uint32_t seed, float *d_offsets, void *stream) {
+	return pixel_offsets(h, nullptr, n, sample, seed, d_offsets, stream);
+}
+int rtgi_hip_pixel_offsets_pixels_device(rtgi_hip_tracer *h, const uint32_t *d_pixels, uint32_t n, uint32_t sample, uint32_t seed,
+                                         float *d_offsets, void *stream) {
+	if (!h) return RTGI_ERR_INVALID;
+	if (n != 0 && !d_pixels) return fail(h, RTGI_ERR_INVALID, "pixel_offsets_pixels: null pixel list");
+	return pixel_offsets(h, d_pixels, n, sample, seed, d_offsets, stream);
+}
+namespace {
+int pixel_offsets(rtgi_hip_tracer *h, const uint32_t *d_pixels, uint32_t n, uint32_t sample, uint32_t seed, float *d_offsets, void *stream) {
 	if (!h) return RTGI_ERR_INVALID;
 	if (h->device < 0) return fail(h, RTGI_ERR_DEVICE, "host-only handle: needs a GPU");
 	if (n == 0) return RTGI_OK;
 	if (!d_offsets || (reinterpret_cast<uintptr_t>(d_offsets) & 7u)) return fail(h, RTGI_ERR_INVALID, "pixel_offsets: null or misaligned buffer");
 	DeviceScope device_scope(h->device);
 	HIP_TRY(h, device_scope.status);
-	hipLaunchKernelGGL(rtgi_dev::pixel_offsets_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (float2 *)d_offsets, n,
-	                   sample, seed);
+	hipLaunchKernelGGL(rtgi_dev::pixel_offsets_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (float2 *)d_offsets,
+	                   d_pixels, n, sample, seed);
+	HIP_TRY(h, hipGetLastError());
+	return RTGI_OK;
+}
+}  // namespace
+
+int rtgi_hip_path_begin_device(rtgi_hip_tracer *h, uint32_t n, float *d_throughput, uint32_t *d_slot, float *d_radiance, void *stream) {
+	if (!h) return RTGI_ERR_INVALID;
+	if (h->device < 0) return fail(h, RTGI_ERR_DEVICE, "host-only handle: needs a GPU");
+	if (n == 0) return RTGI_OK;
+	if (!d_throughput || !d_slot || !d_radiance || ((reinterpret_cast<uintptr_t>(d_throughput) | reinterpret_cast<uintptr_t>(d_radiance)) & 15u))
+		return fail(h, RTGI_ERR_INVALID, "path_begin: null or misaligned buffer");
+	DeviceScope device_scope(h->device);
+	HIP_TRY(h, device_scope.status);
+	hipLaunchKernelGGL(rtgi_dev::path_begin_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (float4 *)d_throughput, d_slot,
+	                   (float4 *)d_radiance, n);
+	HIP_TRY(h, hipGetLastError());
+	return RTGI_OK;
+}
+
+int rtgi_hip_path_add_device(rtgi_hip_tracer *h, const float *d_direct, const float *d_throughput, const uint32_t *d_slot, uint32_t m,
+                             float *d_radiance, void *stream) {
+	if (!h) return RTGI_ERR_INVALID;
+	if (h->device < 0) return fail(h, RTGI_ERR_DEVICE, "host-only handle: needs a GPU");
+	if (m == 0) return RTGI_OK;
+	if (!d_direct || !d_throughput || !d_slot || !d_radiance ||
+	    ((reinterpret_cast<uintptr_t>(d_direct) | reinterpret_cast<uintptr_t>(d_throughput) | reinterpret_cast<uintptr_t>(d_radiance)) & 15u))
+		return fail(h, RTGI_ERR_INVALID, "path_add: null or misaligned buffer");
+	DeviceScope device_scope(h->device);
+	HIP_TRY(h, device_scope.status);
+	hipLaunchKernelGGL(rtgi_dev::path_add_kernel, dim3((m + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float4 *)d_direct,
+	                   (const float4 *)d_throughput, d_slot, m, (float4 *)d_radiance);
+	HIP_TRY(h, hipGetLastError());
+	return RTGI_OK;
+}
+
+int rtgi_hip_path_extend_device(rtgi_hip_tracer *h, const float *d_albedo, const uint32_t *d_parent, uint32_t m,
+                                const float *d_throughput_in, const uint32_t *d_slot_in, float *d_throughput_out, uint32_t *d_slot_out,
+                                void *stream) {
+	if (!h) return RTGI_ERR_INVALID;
+	if (h->device < 0) return fail(h, RTGI_ERR_DEVICE, "host-only handle: needs a GPU");
+	const uint32_t m_max = m;
+	if (m_max == 0) return RTGI_OK;
+	if (!d_albedo || !d_parent || !d_throughput_in || !d_slot_in || !d_throughput_out || !d_slot_out ||
+	    ((reinterpret_cast<uintptr_t>(d_albedo) | reinterpret_cast<uintptr_t>(d_throughput_in) | reinterpret_cast<uintptr_t>(d_throughput_out)) & 15u))
+		return fail(h, RTGI_ERR_INVALID, "path_extend: null or misaligned buffer");
+	DeviceScope device_scope(h->device);
+	HIP_TRY(h, device_scope.status);
+	hipLaunchKernelGGL(rtgi_dev::path_extend_kernel, dim3((m_max + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float4 *)d_albedo,
+	                   d_parent, m_max, (const float4 *)d_throughput_in, d_slot_in, (float4 *)d_throughput_out, d_slot_out);
+	HIP_TRY(h, hipGetLastError());
+	return RTGI_OK;
+}
+
+int rtgi_hip_framebuffer_scatter_device(rtgi_hip_tracer *h, const float *d_part, const uint32_t *d_pixels, uint32_t n, float *d_full,
+                                        void *stream) {
+	if (!h) return RTGI_ERR_INVALID;
+	if (h->device < 0) return fail(h, RTGI_ERR_DEVICE, "host-only handle: needs a GPU");
+	if (n == 0) return RTGI_OK;
+	if (!d_part || !d_pixels || !d_full || ((reinterpret_cast<uintptr_t>(d_part) | reinterpret_cast<uintptr_t>(d_full)) & 15u))
+		return fail(h, RTGI_ERR_INVALID, "framebuffer_scatter: null or misaligned buffer");
+	DeviceScope device_scope(h->device);
+	HIP_TRY(h, device_scope.status);
+	hipLaunchKernelGGL(rtgi_dev::framebuffer_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+	                   (const float4 *)d_part, d_pixels, n, (float4 *)d_full);
+	HIP_TRY(h, hipGetLastError());
+	return RTGI_OK;
+}
+
+int rtgi_hip_framebuffer_sums_device(rtgi_hip_tracer *h, float *d_framebuffer, uint32_t n, int to_sums, void *stream) {
+	if (!h) return RTGI_ERR_INVALID;
+	if (h->device < 0) return fail(h, RTGI_ERR_DEVICE, "host-only handle: needs a GPU");
+	if (n == 0) return RTGI_OK;
+	if (!d_framebuffer || (reinterpret_cast<uintptr_t>(d_framebuffer) & 15u)) return fail(h, RTGI_ERR_INVALID, "framebuffer_sums: null or misaligned buffer");
+	DeviceScope device_scope(h->device);
+	HIP_TRY(h, device_scope.status);
+	hipLaunchKernelGGL(rtgi_dev::framebuffer_sums_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (float4 *)d_framebuffer, n,
+	                   to_sums);
+	HIP_TRY(h, hipGetLastError());
+	return RTGI_OK;
+}
+
+int rtgi_hip_framebuffer_accumulate_device(rtgi_hip_tracer *h, float *d_dst, const float *d_src, uint32_t n, void *stream) {
+	if (!h) return RTGI_ERR_INVALID;
+	if (h->device < 0) return fail(h, RTGI_ERR_DEVICE, "host-only handle: needs a GPU");
+	if (n == 0) return RTGI_OK;
+	if (!d_dst || !d_src || ((reinterpret_cast<uintptr_t>(d_dst) | reinterpret_cast<uintptr_t>(d_src)) & 15u))
+		return fail(h, RTGI_ERR_INVALID, "framebuffer_accumulate: null or misaligned buffer");
+	DeviceScope device_scope(h->device);
+	HIP_TRY(h, device_scope.status);
+	hipLaunchKernelGGL(rtgi_dev::framebuffer_accumulate_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (float4 *)d_dst,
+	                   (const float4 *)d_src, n);
 	HIP_TRY(h, hipGetLastError());
 	return RTGI_OK;
 }
@@ -1343,6 +1466,12 @@ int rtgi_hip_framebuffer_rgb8_device(rtgi_hip_tracer *h, const float *d_framebuf
 int rtgi_hip_bounce_rays_device(rtgi_hip_tracer *h, const rtgi_ray *d_rays, const rtgi_hit *d_hits, uint32_t n,
                                 uint32_t seed, uint32_t bounce, rtgi_ray *d_out, uint32_t *d_parent, uint32_t *d_count,
                                 void *stream) {
+	return rtgi_hip_bounce_rays_keyed_device(h, d_rays, d_hits, n, nullptr, nullptr, seed, bounce, d_out, d_parent, d_count, stream);
+}
+
+int rtgi_hip_bounce_rays_keyed_device(rtgi_hip_tracer *h, const rtgi_ray *d_rays, const rtgi_hit *d_hits, uint32_t n,
+                                      const uint32_t *d_keys, const uint32_t *d_key_table, uint32_t seed, uint32_t bounce,
+                                      rtgi_ray *d_out, uint32_t *d_parent, uint32_t *d_count, void *stream) {
 	if (!h) return RTGI_ERR_INVALID;
 	if (h->device < 0) return fail(h, RTGI_ERR_DEVICE, "host-only handle: needs a GPU");
 	if (!h->built) return fail(h, RTGI_ERR_NOT_BUILT, "no acceleration structure: call build first");
@@ -1372,6 +1501,7 @@ int rtgi_hip_bounce_rays_device(rtgi_hip_tracer *h, const rtgi_ray *d_rays, cons
 	a.block_counts = h->d_block_counts;
 	a.out = (float4 *)d_out;
 	a.parent = d_parent;
+	a.keys = d_keys, a.key_table = d_key_table;
 	a.n = n, a.seed = seed, a.bounce = bounce;
 	if (int rc = scratch_begin(h, st)) return rc;
 	hipLaunchKernelGGL(rtgi_dev::bounce_count_kernel, dim3(n_blocks), dim3(1024), 0, st, a);

@@ -20,13 +20,16 @@ struct CamArgs {
 	int w, h;
 	const float2 *offsets;  // optional sub-pixel jitter per pixel, as the caller's rng would give (camera.cpp:11)
 	float4 *rays;
+	const uint32_t *pixels;  // optional: ray i (and offset i) belongs to pixel pixels[i] = y * w + x, n of them
+	uint32_t n;
 };
 
 // cam_ray, libgi/camera.cpp:11-22, for every pixel (batch_cam_ray_setup_cpu, libgi/wavefront-rt.h:90-102)
 __global__ __launch_bounds__(256) void camera_rays_kernel(CamArgs a) {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-	if (i >= (uint32_t)a.w * (uint32_t)a.h) return;
-	const int x = (int)(i % (uint32_t)a.w), y = (int)(i / (uint32_t)a.w);
+	if (i >= a.n) return;
+	const uint32_t pixel = a.pixels ? a.pixels[i] : i;
+	const int x = (int)(pixel % (uint32_t)a.w), y = (int)(pixel / (uint32_t)a.w);
 	float ox = 0.0f, oy = 0.0f;
 	if (a.offsets) {
 		const float2 o = a.offsets[i];
@@ -106,10 +109,12 @@ __device__ __forceinline__ float uniform01(uint32_t index, uint32_t stream, uint
 
 // Sub-pixel offsets for one sample of every pixel, uniform in [-0.5, 0.5): what the renderer draws from its
 // rng per pixel (gi/primary-hit.cpp:20), here keyed by (pixel, sample, seed) so that a frame is reproducible.
-__global__ __launch_bounds__(256) void pixel_offsets_kernel(float2 *offsets, uint32_t n, uint32_t sample, uint32_t seed) {
+__global__ __launch_bounds__(256) void pixel_offsets_kernel(float2 *offsets, const uint32_t *pixels, uint32_t n, uint32_t sample,
+                                                            uint32_t seed) {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= n) return;
-	offsets[i] = make_float2(uniform01(i, 2u * sample, seed) - 0.5f, uniform01(i, 2u * sample + 1u, seed) - 0.5f);
+	const uint32_t pixel = pixels ? pixels[i] : i;  // the key is the pixel, wherever in the batch its ray sits
+	offsets[i] = make_float2(uniform01(pixel, 2u * sample, seed) - 0.5f, uniform01(pixel, 2u * sample + 1u, seed) - 0.5f);
 }
 
 struct BounceArgs {
@@ -119,6 +124,9 @@ struct BounceArgs {
 	uint32_t *block_counts;  // per 1024 rays: pass 1 out, pass 2 in (after the exclusive scan: offsets)
 	float4 *out;
 	uint32_t *parent;  // optional: index of the ray each bounce ray continues
+	// what the random numbers of ray i are keyed by: i itself, or keys[i], or key_table[keys[i]] (a pixel id that
+	// stays the same however the frame's rays are batched)
+	const uint32_t *keys, *key_table;
 	uint32_t n, seed, bounce;
 };
 
@@ -188,7 +196,9 @@ __global__ __launch_bounds__(1024) void bounce_write_kernel(BounceArgs a) {
 	nx /= nl, ny /= nl, nz /= nl;
 	const float4 r0 = a.rays[2 * (size_t)i], r1 = a.rays[2 * (size_t)i + 1];
 	if (nx * r0.w + ny * r1.x + nz * r1.y > 0.0f) nx = -nx, ny = -ny, nz = -nz;
-	const float u1 = uniform01(i, 2u * a.bounce, a.seed), u2 = uniform01(i, 2u * a.bounce + 1u, a.seed);
+	uint32_t key = a.keys ? a.keys[i] : i;
+	if (a.key_table) key = a.key_table[key];
+	const float u1 = uniform01(key, 2u * a.bounce, a.seed), u2 = uniform01(key, 2u * a.bounce + 1u, a.seed);
 	const float r = sqrtf(u1), phi = 6.2831853071795864769f * u2;
 	float sn, cs;
 	sincosf(phi, &sn, &cs);
@@ -280,6 +290,65 @@ __global__ __launch_bounds__(256) void framebuffer_add_kernel(float4 *fb, const 
 	const float4 c = fb[i], r = radiance[i];
 	const float new_count = c.w + 1.0f;
 	fb[i] = make_float4((c.x * c.w + r.x) / new_count, (c.y * c.w + r.y) / new_count, (c.z * c.w + r.z) / new_count, new_count);
+}
+
+// Paths of more than one segment (no counterpart in the reference, whose algorithms stop at the first hit): a ray
+// of segment k carries the product of the albedos its path has met (cosine-weighted sampling of a lambertian
+// surface has weight albedo) and the slot of the pixel sample it contributes to.
+// begin: throughput 1, slot i, radiance 0 for the n camera rays of a sample.
+__global__ __launch_bounds__(256) void path_begin_kernel(float4 *throughput, uint32_t *slot, float4 *radiance, uint32_t n) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	throughput[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+	slot[i] = i;
+	radiance[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+// add: what the light sends to the path's vertex, weighted: radiance[slot[j]] += throughput[j] * direct[j]. Every
+// slot occurs at most once among the m rays of a segment, so plain stores do.
+__global__ __launch_bounds__(256) void path_add_kernel(const float4 *direct, const float4 *throughput, const uint32_t *slot, uint32_t m,
+                                                       float4 *radiance) {
+	const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+	if (j >= m) return;
+	const float4 d = direct[j], t = throughput[j];
+	const uint32_t s = slot[j];
+	const float4 r = radiance[s];
+	radiance[s] = make_float4(r.x + t.x * d.x, r.y + t.y * d.y, r.z + t.z * d.z, 0.0f);
+}
+// extend: the rays of the next segment (ray j continues ray parent[j]) inherit slot and throughput * albedo.
+__global__ __launch_bounds__(256) void path_extend_kernel(const float4 *albedo, const uint32_t *parent, uint32_t m, const float4 *throughput_in,
+                                                          const uint32_t *slot_in, float4 *throughput_out, uint32_t *slot_out) {
+	const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+	if (j >= m) return;
+	const uint32_t p = parent[j];
+	const float4 t = throughput_in[p], a = albedo[p];
+	throughput_out[j] = make_float4(t.x * a.x, t.y * a.y, t.z * a.z, 0.0f);
+	slot_out[j] = slot_in[p];
+}
+
+// The framebuffer of a frame that several GPUs rendered parts of. Each GPU accumulates its pixels (or its samples)
+// like framebuffer::add does; the parts are then combined as sums and counts, never as means (a running mean with
+// its count in .w, libgi/framebuffer.cpp:10-18, is only meaningful together with that count).
+// full[pixels[i]] = part[i]: a GPU's densely stored pixels into their places in the frame.
+__global__ __launch_bounds__(256) void framebuffer_scatter_kernel(const float4 *part, const uint32_t *pixels, uint32_t n, float4 *full) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i < n) full[pixels[i]] = part[i];
+}
+// (mean rgb, count) -> (sum rgb, count) and back; a pixel without samples stays (0, 0, 0, 0)
+__global__ __launch_bounds__(256) void framebuffer_sums_kernel(float4 *fb, uint32_t n, int to_sums) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	float4 c = fb[i];
+	if (to_sums)
+		c.x *= c.w, c.y *= c.w, c.z *= c.w;
+	else if (c.w > 0.0f)
+		c.x /= c.w, c.y /= c.w, c.z /= c.w;
+	fb[i] = c;
+}
+__global__ __launch_bounds__(256) void framebuffer_accumulate_kernel(float4 *dst, const float4 *src, uint32_t n) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	const float4 a = dst[i], b = src[i];
+	dst[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
 }
 
 // framebuffer::png, libgi/framebuffer.cpp:21-30: clamp to [0,1], gamma 1/2.2, scale to 255, truncate to a

@@ -28,7 +28,9 @@ EXPORTS = [
     "rtgi_hip_get_nodes", "rtgi_hip_get_triangle_order", "rtgi_hip_closest_hit", "rtgi_hip_any_hit",
     "rtgi_hip_host_alloc", "rtgi_hip_host_free", "rtgi_hip_host_register", "rtgi_hip_host_unregister",
     "rtgi_hip_closest_hit_device", "rtgi_hip_any_hit_device", "rtgi_hip_closest_hit_device_noalloc", "rtgi_hip_trace_batches_device", "rtgi_hip_camera_rays_device",
-    "rtgi_hip_pixel_offsets_device", "rtgi_hip_shadow_rays_device", "rtgi_hip_bounce_rays_device", "rtgi_hip_set_shading",
+    "rtgi_hip_pixel_offsets_device", "rtgi_hip_pixel_offsets_pixels_device", "rtgi_hip_camera_rays_pixels_device",
+    "rtgi_hip_bounce_rays_keyed_device", "rtgi_hip_path_begin_device", "rtgi_hip_path_add_device", "rtgi_hip_path_extend_device",
+    "rtgi_hip_framebuffer_scatter_device", "rtgi_hip_framebuffer_sums_device", "rtgi_hip_framebuffer_accumulate_device", "rtgi_hip_shadow_rays_device", "rtgi_hip_bounce_rays_device", "rtgi_hip_set_shading",
     "rtgi_hip_shade_primary_device", "rtgi_hip_shade_local_device", "rtgi_hip_framebuffer_add_device",
     "rtgi_hip_framebuffer_rgb8_device", "rtgi_hip_profile_begin", "rtgi_hip_profile_end", "rtgi_hip_profile_work",
     "rtgi_hip_last_error",
@@ -86,6 +88,15 @@ def lib():
         L.rtgi_hip_shadow_rays_device.argtypes = [vp, vp, u32, vp, vp, vp]
         L.rtgi_hip_bounce_rays_device.argtypes = [vp, vp, vp, u32, u32, u32, vp, vp, vp, vp]
         L.rtgi_hip_pixel_offsets_device.argtypes = [vp, u32, u32, u32, vp, vp]
+        L.rtgi_hip_pixel_offsets_pixels_device.argtypes = [vp, vp, u32, u32, u32, vp, vp]
+        L.rtgi_hip_camera_rays_pixels_device.argtypes = [vp, vp, vp, u32, vp, vp, vp]
+        L.rtgi_hip_bounce_rays_keyed_device.argtypes = [vp, vp, vp, u32, vp, vp, u32, u32, vp, vp, vp, vp]
+        L.rtgi_hip_path_begin_device.argtypes = [vp, u32, vp, vp, vp, vp]
+        L.rtgi_hip_path_add_device.argtypes = [vp, vp, vp, vp, u32, vp, vp]
+        L.rtgi_hip_path_extend_device.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp, vp]
+        L.rtgi_hip_framebuffer_scatter_device.argtypes = [vp, vp, vp, u32, vp, vp]
+        L.rtgi_hip_framebuffer_sums_device.argtypes = [vp, vp, u32, i32, vp]
+        L.rtgi_hip_framebuffer_accumulate_device.argtypes = [vp, vp, vp, u32, vp]
         L.rtgi_hip_set_shading.argtypes = [vp, vp, sz, u32, vp, sz, u32, vp, u32]
         L.rtgi_hip_shade_primary_device.argtypes = [vp, vp, u32, vp, vp]
         L.rtgi_hip_shade_local_device.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp]
