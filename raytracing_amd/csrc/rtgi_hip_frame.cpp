@@ -1,0 +1,434 @@
+// rtgi_hip_frame.cpp -- whole frames of the wavefront algorithms on one or several GPUs (C ABI of
+// include/rtgi_hip_frame.h). Host code only: every stage is a call into librtgi_hip.so, the exchange between GPUs is
+// one RCCL all-reduce of the framebuffer. One host thread and one stream per GPU.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <exception>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "rtgi_hip_frame.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+double now_ms() {
+	using namespace std::chrono;
+	return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+// One GPU's share of the renderer: its tracer handle, its stream and its buffers (all sized for `cap` pixels).
+struct Part {
+	int device = 0;
+	rtgi_hip_tracer *h = nullptr;
+	hipStream_t stream = nullptr;
+	ncclComm_t comm = nullptr;
+	std::string error;
+	int rc = RTGI_OK;
+
+	// this frame's pixels (tile sharding: this GPU's tiles; else all) and samples
+	std::vector<uint32_t> pixels;
+	bool all_pixels = true;
+	uint32_t n = 0;  // pixels of this part
+	uint64_t rays = 0;
+	double t_traced = 0.0;
+
+	size_t cap = 0, cap_full = 0;
+	uint32_t *d_pixels = nullptr, *d_slot[2] = {nullptr, nullptr}, *d_parent = nullptr, *d_count = nullptr;
+	float *d_offsets = nullptr, *d_direct = nullptr, *d_albedo = nullptr, *d_throughput[2] = {nullptr, nullptr};
+	float *d_radiance = nullptr, *d_fb = nullptr, *d_full = nullptr;
+	rtgi_ray *d_rays[2] = {nullptr, nullptr}, *d_shadow = nullptr;
+	rtgi_hit *d_hits = nullptr;
+	uint8_t *d_occluded = nullptr, *d_rgb = nullptr;
+};
+
+}  // namespace
+
+struct rtgi_hip_renderer {
+	std::vector<Part> parts;
+	bool distinct = true;  // every part on a GPU of its own: RCCL combines the framebuffers
+	bool comms_ready = false;
+	std::string error;
+};
+
+namespace {
+
+int fail(rtgi_hip_renderer *r, int code, const std::string &msg) {
+	if (r) r->error = msg;
+	return code;
+}
+int fail(Part &p, int code, const std::string &msg) {
+	p.error = msg;
+	p.rc = code;
+	return code;
+}
+
+#define PART_HIP(p, expr)                                                                                   \
+	do {                                                                                                    \
+		hipError_t e_ = (expr);                                                                             \
+		if (e_ != hipSuccess) return fail(p, RTGI_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+	} while (0)
+#define PART_RT(p, expr)                                                                     \
+	do {                                                                                     \
+		int rc_ = (expr);                                                                    \
+		if (rc_ < 0) return fail(p, rc_, std::string(#expr) + ": " + rtgi_hip_last_error((p).h)); \
+	} while (0)
+
+void free_buffers(Part &p) {
+	if (hipSetDevice(p.device) != hipSuccess) return;
+	void *all[] = {p.d_pixels, p.d_slot[0], p.d_slot[1], p.d_parent, p.d_count, p.d_offsets, p.d_direct, p.d_albedo, p.d_throughput[0],
+	               p.d_throughput[1], p.d_radiance, p.d_fb, p.d_full, p.d_rays[0], p.d_rays[1], p.d_shadow, p.d_hits, p.d_occluded, p.d_rgb};
+	for (void *q : all)
+		if (q) (void)hipFree(q);
+	p.d_pixels = p.d_slot[0] = p.d_slot[1] = p.d_parent = p.d_count = nullptr;
+	p.d_offsets = p.d_direct = p.d_albedo = p.d_throughput[0] = p.d_throughput[1] = p.d_radiance = p.d_fb = p.d_full = nullptr;
+	p.d_rays[0] = p.d_rays[1] = p.d_shadow = nullptr;
+	p.d_hits = nullptr;
+	p.d_occluded = p.d_rgb = nullptr;
+	p.cap = p.cap_full = 0;
+}
+
+// Buffers for n pixels of this part and a frame of n_full pixels; kept between frames, grown on demand.
+int ensure_buffers(Part &p, size_t n, size_t n_full) {
+	if (n <= p.cap && n_full <= p.cap_full) return RTGI_OK;
+	free_buffers(p);
+	PART_HIP(p, hipSetDevice(p.device));
+	const size_t c = std::max<size_t>(n, 1), f = std::max<size_t>(n_full, 1);
+	PART_HIP(p, hipMalloc((void **)&p.d_pixels, c * 4));
+	PART_HIP(p, hipMalloc((void **)&p.d_slot[0], c * 4));
+	PART_HIP(p, hipMalloc((void **)&p.d_slot[1], c * 4));
+	PART_HIP(p, hipMalloc((void **)&p.d_parent, c * 4));
+	PART_HIP(p, hipMalloc((void **)&p.d_count, 256));
+	PART_HIP(p, hipMalloc((void **)&p.d_offsets, c * 8));
+	PART_HIP(p, hipMalloc((void **)&p.d_direct, c * 16));
+	PART_HIP(p, hipMalloc((void **)&p.d_albedo, c * 16));
+	PART_HIP(p, hipMalloc((void **)&p.d_throughput[0], c * 16));
+	PART_HIP(p, hipMalloc((void **)&p.d_throughput[1], c * 16));
+	PART_HIP(p, hipMalloc((void **)&p.d_radiance, c * 16));
+	PART_HIP(p, hipMalloc((void **)&p.d_fb, c * 16));
+	PART_HIP(p, hipMalloc((void **)&p.d_full, f * 16));
+	PART_HIP(p, hipMalloc((void **)&p.d_rays[0], c * sizeof(rtgi_ray)));
+	PART_HIP(p, hipMalloc((void **)&p.d_rays[1], c * sizeof(rtgi_ray)));
+	PART_HIP(p, hipMalloc((void **)&p.d_shadow, c * sizeof(rtgi_ray)));
+	PART_HIP(p, hipMalloc((void **)&p.d_hits, c * sizeof(rtgi_hit)));
+	PART_HIP(p, hipMalloc((void **)&p.d_occluded, c));
+	PART_HIP(p, hipMalloc((void **)&p.d_rgb, f * 3));
+	p.cap = c;
+	p.cap_full = f;
+	return RTGI_OK;
+}
+
+// The pixels of every `world`-th tile starting with tile `rank`, tiles numbered row by row, pixels of a tile row by
+// row: neighbouring rays of a batch are neighbours in the image.
+void tile_pixels(int w, int h, uint32_t tile, int world, int rank, std::vector<uint32_t> &out) {
+	out.clear();
+	int t = 0;
+	for (int y0 = 0; y0 < h; y0 += (int)tile)
+		for (int x0 = 0; x0 < w; x0 += (int)tile, ++t) {
+			if (t % world != rank) continue;
+			for (int y = y0; y < std::min(h, y0 + (int)tile); ++y)
+				for (int x = x0; x < std::min(w, x0 + (int)tile); ++x) out.push_back((uint32_t)y * (uint32_t)w + (uint32_t)x);
+		}
+}
+
+// This part's share of the frame, up to its framebuffer in place in p.d_full (zero where it has no samples).
+int render_part(Part &p, const rtgi_frame &f, int rank, int world) {
+	PART_HIP(p, hipSetDevice(p.device));
+	const uint32_t n_full = (uint32_t)f.cam.w * (uint32_t)f.cam.h;
+	const bool by_tiles = world > 1 && f.sharding == RTGI_SHARD_TILES;
+	p.all_pixels = !by_tiles;
+	if (by_tiles)
+		tile_pixels(f.cam.w, f.cam.h, f.tile ? f.tile : 64u, world, rank, p.pixels);
+	p.n = by_tiles ? (uint32_t)p.pixels.size() : n_full;
+	p.rays = 0;
+	if (int rc = ensure_buffers(p, p.n, n_full)) return rc;
+	hipStream_t st = p.stream;
+	const uint32_t n = p.n;
+	const uint32_t *d_pixels = nullptr;
+	if (by_tiles) {
+		PART_HIP(p, hipMemcpyAsync(p.d_pixels, p.pixels.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+		d_pixels = p.d_pixels;
+	}
+	float *fb = by_tiles ? p.d_fb : p.d_full;  // framebuffer::clear
+	PART_HIP(p, hipMemsetAsync(fb, 0, (size_t)std::max<uint32_t>(n, 1) * 16, st));
+	const int step = (world > 1 && f.sharding == RTGI_SHARD_SAMPLES) ? world : 1;
+	const int first = step > 1 ? rank : 0;
+	for (uint32_t sample = (uint32_t)first; sample < f.sppx && n > 0; sample += (uint32_t)step) {
+		const float *offsets = nullptr;
+		if (f.jitter) {
+			if (d_pixels)
+				PART_RT(p, rtgi_hip_pixel_offsets_pixels_device(p.h, d_pixels, n, sample, f.seed, p.d_offsets, st));
+			else
+				PART_RT(p, rtgi_hip_pixel_offsets_device(p.h, n, sample, f.seed, p.d_offsets, st));
+			offsets = p.d_offsets;
+		}
+		if (d_pixels)
+			PART_RT(p, rtgi_hip_camera_rays_pixels_device(p.h, &f.cam, d_pixels, n, offsets, p.d_rays[0], st));
+		else
+			PART_RT(p, rtgi_hip_camera_rays_device(p.h, &f.cam, offsets, p.d_rays[0], st));
+		PART_RT(p, rtgi_hip_closest_hit_device(p.h, p.d_rays[0], n, p.d_hits, nullptr, st));
+		p.rays += n;
+		if (f.algo == RTGI_ALGO_PRIMARY) {
+			PART_RT(p, rtgi_hip_shade_primary_device(p.h, p.d_hits, n, p.d_radiance, st));
+		} else if (f.algo == RTGI_ALGO_LOCAL) {
+			PART_RT(p, rtgi_hip_shadow_rays_device(p.h, p.d_hits, n, f.light_pos, p.d_shadow, st));
+			PART_RT(p, rtgi_hip_any_hit_device(p.h, p.d_shadow, n, p.d_occluded, nullptr, st));
+			p.rays += n;
+			PART_RT(p, rtgi_hip_shade_local_device(p.h, p.d_hits, p.d_occluded, n, f.light_pos, f.light_col, p.d_radiance, st));
+		} else {
+			// a path per pixel sample: light every vertex, then follow one diffuse bounce, `bounces` times
+			PART_RT(p, rtgi_hip_path_begin_device(p.h, n, p.d_throughput[0], p.d_slot[0], p.d_radiance, st));
+			uint32_t m = n;
+			int cur = 0;
+			for (uint32_t depth = 0;; ++depth) {
+				if (depth > 0) {
+					PART_RT(p, rtgi_hip_closest_hit_device(p.h, p.d_rays[cur], m, p.d_hits, nullptr, st));
+					p.rays += m;
+				}
+				PART_RT(p, rtgi_hip_shadow_rays_device(p.h, p.d_hits, m, f.light_pos, p.d_shadow, st));
+				PART_RT(p, rtgi_hip_any_hit_device(p.h, p.d_shadow, m, p.d_occluded, nullptr, st));
+				p.rays += m;
+				PART_RT(p, rtgi_hip_shade_local_device(p.h, p.d_hits, p.d_occluded, m, f.light_pos, f.light_col, p.d_direct, st));
+				PART_RT(p, rtgi_hip_path_add_device(p.h, p.d_direct, p.d_throughput[cur], p.d_slot[cur], m, p.d_radiance, st));
+				if (depth == f.bounces) break;
+				PART_RT(p, rtgi_hip_shade_primary_device(p.h, p.d_hits, m, p.d_albedo, st));
+				// (seed: one stream of numbers per sample; keys: the pixel, so that a path does not depend on the sharding)
+				PART_RT(p, rtgi_hip_bounce_rays_keyed_device(p.h, p.d_rays[cur], p.d_hits, m, p.d_slot[cur], d_pixels,
+				                                             f.seed * 0x9E3779B1u + sample, depth + 1, p.d_rays[1 - cur], p.d_parent, p.d_count, st));
+				uint32_t next = 0;  // the number of rays that go on is needed on the host: the next launches are sized by it
+				PART_HIP(p, hipMemcpyAsync(&next, p.d_count, 4, hipMemcpyDeviceToHost, st));
+				PART_HIP(p, hipStreamSynchronize(st));
+				if (next == 0) break;
+				PART_RT(p, rtgi_hip_path_extend_device(p.h, p.d_albedo, p.d_parent, next, p.d_throughput[cur], p.d_slot[cur],
+				                                       p.d_throughput[1 - cur], p.d_slot[1 - cur], st));
+				cur = 1 - cur;
+				m = next;
+			}
+		}
+		PART_RT(p, rtgi_hip_framebuffer_add_device(p.h, fb, p.d_radiance, n, st));
+	}
+	if (by_tiles) {
+		PART_HIP(p, hipMemsetAsync(p.d_full, 0, (size_t)n_full * 16, st));
+		PART_RT(p, rtgi_hip_framebuffer_scatter_device(p.h, p.d_fb, d_pixels, n, p.d_full, st));
+	}
+	if (world > 1 && f.sharding == RTGI_SHARD_SAMPLES) PART_RT(p, rtgi_hip_framebuffer_sums_device(p.h, p.d_full, n_full, 1, st));
+	PART_HIP(p, hipStreamSynchronize(st));
+	p.t_traced = now_ms();
+	return RTGI_OK;
+}
+
+int check_frame(rtgi_hip_renderer *r, const rtgi_frame *f) {
+	if (!f) return fail(r, RTGI_ERR_INVALID, "render: null frame");
+	if (f->cam.w <= 0 || f->cam.h <= 0 || (uint64_t)f->cam.w * (uint64_t)f->cam.h > 0x7fffffffull)
+		return fail(r, RTGI_ERR_INVALID, "render: bad resolution");
+	if (f->sppx == 0) return fail(r, RTGI_ERR_INVALID, "render: sppx must be positive");
+	if (f->algo > RTGI_ALGO_PATH) return fail(r, RTGI_ERR_INVALID, "render: no such algorithm");
+	if (f->sharding > RTGI_SHARD_SAMPLES) return fail(r, RTGI_ERR_INVALID, "render: no such sharding");
+	if (f->bounces > 64) return fail(r, RTGI_ERR_INVALID, "render: at most 64 bounces");
+	return RTGI_OK;
+}
+
+// Runs fn(part index) for every part, on a thread of its own when there are several; a part's failure is kept in it.
+template <class F>
+int for_each_part(rtgi_hip_renderer *r, F fn) {
+	const int n = (int)r->parts.size();
+	for (Part &p : r->parts) p.rc = RTGI_OK, p.error.clear();
+	if (n == 1)
+		fn(0);
+	else {
+		std::vector<std::thread> threads;
+		try {
+			for (int i = 1; i < n; ++i) threads.emplace_back([&fn, i] { fn(i); });
+		} catch (const std::exception &e) {
+			for (std::thread &t : threads) t.join();
+			return fail(r, RTGI_ERR_NOMEM, std::string("cannot start a host thread per GPU: ") + e.what());
+		}
+		fn(0);
+		for (std::thread &t : threads) t.join();
+	}
+	for (int i = 0; i < n; ++i)
+		if (r->parts[i].rc < 0) return fail(r, r->parts[i].rc, "GPU " + std::to_string(r->parts[i].device) + " (part " + std::to_string(i) + "): " + r->parts[i].error);
+	return RTGI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+rtgi_hip_renderer *rtgi_hip_renderer_create(const int *devices, int n, int layout, int esc) {
+	if (!devices || n < 1 || n > 64) {
+		g_create_error = "renderer_create: between 1 and 64 devices";
+		return nullptr;
+	}
+	rtgi_hip_renderer *r = new (std::nothrow) rtgi_hip_renderer;
+	if (!r) {
+		g_create_error = "out of memory";
+		return nullptr;
+	}
+	try {
+		r->parts.resize((size_t)n);
+	} catch (const std::exception &) {
+		delete r;
+		g_create_error = "out of memory";
+		return nullptr;
+	}
+	for (int i = 0; i < n; ++i)
+		for (int j = 0; j < i; ++j)
+			if (devices[i] == devices[j]) r->distinct = false;
+	for (int i = 0; i < n; ++i) {
+		Part &p = r->parts[(size_t)i];
+		p.device = devices[i];
+		p.h = rtgi_hip_create(devices[i], layout, esc);
+		if (!p.h) {
+			g_create_error = rtgi_hip_last_error(nullptr);
+			rtgi_hip_renderer_destroy(r);
+			return nullptr;
+		}
+		hipError_t e = hipSetDevice(p.device);
+		if (e == hipSuccess) e = hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking);
+		if (e != hipSuccess) {
+			g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
+			rtgi_hip_renderer_destroy(r);
+			return nullptr;
+		}
+	}
+	return r;
+}
+
+void rtgi_hip_renderer_destroy(rtgi_hip_renderer *r) {
+	if (!r) return;
+	for (Part &p : r->parts) {
+		free_buffers(p);
+		if (p.comm) (void)ncclCommDestroy(p.comm);
+		if (p.stream && hipSetDevice(p.device) == hipSuccess) (void)hipStreamDestroy(p.stream);
+		if (p.h) rtgi_hip_destroy(p.h);
+	}
+	delete r;
+}
+
+int rtgi_hip_renderer_device_count(const rtgi_hip_renderer *r) { return r ? (int)r->parts.size() : 0; }
+
+rtgi_hip_tracer *rtgi_hip_renderer_handle(rtgi_hip_renderer *r, int i) {
+	return (r && i >= 0 && i < (int)r->parts.size()) ? r->parts[(size_t)i].h : nullptr;
+}
+
+int rtgi_hip_renderer_interprete(rtgi_hip_renderer *r, const char *command, const char *args) {
+	if (!r) return RTGI_ERR_INVALID;
+	int result = 0;
+	for (size_t i = 0; i < r->parts.size(); ++i) {
+		// ("bvh statistics" and "bvh export" print or write once)
+		const std::string a = args ? args : "";
+		if (i > 0 && command && std::string(command) == "bvh" && (a.find("statistics") != std::string::npos || a.find("export") != std::string::npos)) continue;
+		const int rc = rtgi_hip_interprete(r->parts[i].h, command, args);
+		if (rc < 0) return fail(r, rc, rtgi_hip_last_error(r->parts[i].h));
+		if (i == 0) result = rc;
+	}
+	return result;
+}
+
+int rtgi_hip_renderer_build(rtgi_hip_renderer *r, const void *vertices, size_t vertex_stride, uint32_t n_vertices, const void *triangles,
+                            size_t tri_stride, uint32_t n_triangles, const float *albedo_rgb, uint32_t n_materials) {
+	if (!r) return RTGI_ERR_INVALID;
+	if (!vertices || !triangles) return fail(r, RTGI_ERR_INVALID, "there is no scene data to work with");
+	if (vertex_stride < 24 || tri_stride < 16) return fail(r, RTGI_ERR_INVALID, "renderer_build: vertex records need position and normal, triangle records a material id");
+	return for_each_part(r, [&](int i) {
+		Part &p = r->parts[(size_t)i];
+		int rc = rtgi_hip_build(p.h, vertices, vertex_stride, n_vertices, triangles, tri_stride, n_triangles);
+		if (rc == RTGI_OK && albedo_rgb && n_materials)
+			rc = rtgi_hip_set_shading(p.h, (const char *)vertices + 12, vertex_stride, n_vertices, triangles, tri_stride, n_triangles, albedo_rgb,
+			                          n_materials);
+		if (rc < 0) fail(p, rc, rtgi_hip_last_error(p.h));
+	});
+}
+
+int rtgi_hip_renderer_render(rtgi_hip_renderer *r, const rtgi_frame *frame, float *framebuffer, uint8_t *rgb8, rtgi_frame_stats *stats) {
+	if (!r) return RTGI_ERR_INVALID;
+	if (int rc = check_frame(r, frame)) return rc;
+	const rtgi_frame f = *frame;
+	const int world = (int)r->parts.size();
+	const uint32_t n_full = (uint32_t)f.cam.w * (uint32_t)f.cam.h;
+	const double t0 = now_ms();
+	// communicators for the framebuffer exchange, once: one rank per GPU, all in this process
+	if (world > 1 && r->distinct && !r->comms_ready) {
+		std::vector<ncclComm_t> comms((size_t)world);
+		std::vector<int> devs((size_t)world);
+		for (int i = 0; i < world; ++i) devs[(size_t)i] = r->parts[(size_t)i].device;
+		const ncclResult_t e = ncclCommInitAll(comms.data(), world, devs.data());
+		if (e != ncclSuccess) return fail(r, RTGI_ERR_DEVICE, std::string("ncclCommInitAll: ") + ncclGetErrorString(e));
+		for (int i = 0; i < world; ++i) r->parts[(size_t)i].comm = comms[(size_t)i];
+		r->comms_ready = true;
+	}
+	int rc = for_each_part(r, [&](int i) { render_part(r->parts[(size_t)i], f, i, world); });
+	if (rc) return rc;
+	double t_traced = t0;
+	for (const Part &p : r->parts) t_traced = std::max(t_traced, p.t_traced);
+	// ---- the one exchange of a frame: framebuffers as sums and counts (tiles: every pixel has one owner, the
+	// others hold zeros, and x + 0 = x keeps the owner's value to the bit) ----
+	bool used_rccl = false;
+	if (world > 1) {
+		if (r->distinct) {
+			rc = for_each_part(r, [&](int i) {
+				Part &p = r->parts[(size_t)i];
+				if (hipSetDevice(p.device) != hipSuccess) {
+					fail(p, RTGI_ERR_DEVICE, "hipSetDevice");
+					return;
+				}
+				const ncclResult_t e = ncclAllReduce(p.d_full, p.d_full, (size_t)n_full * 4, ncclFloat, ncclSum, p.comm, p.stream);
+				if (e != ncclSuccess) {
+					fail(p, RTGI_ERR_DEVICE, std::string("ncclAllReduce: ") + ncclGetErrorString(e));
+					return;
+				}
+				const hipError_t he = hipStreamSynchronize(p.stream);
+				if (he != hipSuccess) fail(p, RTGI_ERR_DEVICE, std::string("after ncclAllReduce: ") + hipGetErrorString(he));
+			});
+			if (rc) return rc;
+			used_rccl = true;
+		} else {
+			// handles that share a GPU (a rehearsal of the multi-GPU path): the same sum by a kernel on that GPU
+			Part &p0 = r->parts[0];
+			for (int i = 1; i < world; ++i) {
+				if (r->parts[(size_t)i].device != p0.device) return fail(r, RTGI_ERR_INVALID, "a GPU may be named twice only if all parts share one GPU");
+				const int arc = rtgi_hip_framebuffer_accumulate_device(p0.h, p0.d_full, r->parts[(size_t)i].d_full, n_full, p0.stream);
+				if (arc < 0) return fail(r, arc, rtgi_hip_last_error(p0.h));
+			}
+		}
+		if (f.sharding == RTGI_SHARD_SAMPLES) {
+			const int src = rtgi_hip_framebuffer_sums_device(r->parts[0].h, r->parts[0].d_full, n_full, 0, r->parts[0].stream);
+			if (src < 0) return fail(r, src, rtgi_hip_last_error(r->parts[0].h));
+		}
+	}
+	Part &p0 = r->parts[0];
+	if (hipSetDevice(p0.device) != hipSuccess) return fail(r, RTGI_ERR_DEVICE, "hipSetDevice");
+	hipError_t e = hipStreamSynchronize(p0.stream);
+	const double t_reduced = now_ms();
+	if (e == hipSuccess && framebuffer) e = hipMemcpyAsync(framebuffer, p0.d_full, (size_t)n_full * 16, hipMemcpyDeviceToHost, p0.stream);
+	if (e == hipSuccess && rgb8) {
+		const int qrc = rtgi_hip_framebuffer_rgb8_device(p0.h, p0.d_full, (uint32_t)f.cam.w, (uint32_t)f.cam.h, p0.d_rgb, p0.stream);
+		if (qrc < 0) return fail(r, qrc, rtgi_hip_last_error(p0.h));
+		e = hipMemcpyAsync(rgb8, p0.d_rgb, (size_t)n_full * 3, hipMemcpyDeviceToHost, p0.stream);
+	}
+	if (e == hipSuccess) e = hipStreamSynchronize(p0.stream);
+	if (e != hipSuccess) return fail(r, RTGI_ERR_DEVICE, std::string("reading the frame back: ") + hipGetErrorString(e));
+	if (stats) {
+		stats->ms_total = now_ms() - t0;
+		stats->ms_trace = t_traced - t0;
+		stats->ms_reduce = world > 1 ? t_reduced - t_traced : 0.0;
+		stats->rays = 0;
+		for (const Part &p : r->parts) stats->rays += p.rays;
+		stats->n_devices = world;
+		stats->used_rccl = used_rccl ? 1 : 0;
+	}
+	return RTGI_OK;
+}
+
+const char *rtgi_hip_renderer_last_error(const rtgi_hip_renderer *r) { return r ? r->error.c_str() : g_create_error.c_str(); }
+
+}  // extern "C"
