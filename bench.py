@@ -57,6 +57,12 @@ def parse_args():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL; gloo only to rehearse the launch on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--frame", action="store_true",
+                    help="other mode: whole path-traced frames through the C++ frame level (librtgi_hip_frame.so), tiles dealt "
+                         "over the GPUs, framebuffer all-reduce (RCCL, called from C++) inside the timed region")
+    ap.add_argument("--sppx", type=int, default=64, help="--frame: samples per pixel")
+    ap.add_argument("--bounces", type=int, default=1, help="--frame: path segments after the camera ray")
+    ap.add_argument("--sharding", default="tiles", choices=["tiles", "samples"], help="--frame: how a frame is dealt over the GPUs")
     ap.add_argument("--presort", default="none", choices=["none", "morton", "octant_morton", "morton_octant", "random"],
                     help="experiment: reorder the bounce batch on the host before the timed region")
     return ap.parse_args()
@@ -268,6 +274,12 @@ def main():
     elif args.gpus != 1:
         raise SystemExit("--gpus %d needs to be launched through torch.distributed.run" % args.gpus)
     torch.cuda.set_device(device)
+    if args.frame:
+        frame_mode(args, world, rank, device)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     w = build_workload(args, rank, device)
     t = w["tracer"]
@@ -350,6 +362,78 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def frame_mode(args, world, rank, device):
+    """One step = one frame of `sppx` samples per pixel, path-traced (camera ray, `bounces` diffuse bounces, a shadow
+    ray at every vertex) by the C++ frame loop: every rank renders its 64x64 tiles with the whole BVH on its GPU, then
+    one ncclAllReduce of the framebuffer (sums and counts), all inside the timed region."""
+    import torch
+    import torch.distributed as dist
+    from raytracing_amd import frame, scenes
+    gen, kw, cam_pos, cam_dir, cam_up = WORKLOADS[args.workload]
+    pos, tri, nrm = getattr(scenes, gen)(**kw)
+    cam_dir = np.asarray(cam_dir, np.float32) / np.float32(np.linalg.norm(cam_dir))
+    dev = "cuda:%d" % device if args.backend == "nccl" else "cpu"
+    uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        uid = torch.tensor(list(frame.HipRenderer.unique_id()), dtype=torch.uint8, device=dev)
+    if world > 1:
+        dist.broadcast(uid, 0)
+    r = frame.HipRenderer(devices=(device,), layout=args.layout, rank=rank, world=world, unique_id=bytes(uid.cpu().tolist()))
+    for cmd in [c.strip() for c in args.bvh.split(";") if c.strip()]:
+        r.interprete("bvh", cmd)
+    t0 = time.time()
+    r.build(pos, nrm, tri, np.zeros(len(tri), np.uint32), np.array([[0.7, 0.7, 0.7]], np.float32))
+    build_s = time.time() - t0
+    lo, hi = pos.min(0), pos.max(0)
+    light = tuple(float(v) for v in (lo + hi) / 2 + (hi - lo) * np.array([0.15, 0.35, 0.2]))
+    kwr = dict(cam_dir=cam_dir, cam_pos=cam_pos, cam_up=cam_up, fovy=65.0, w=args.width, h=args.height, algo="path",
+               bounces=args.bounces, light_pos=light, light_col=(1.0, 1.0, 1.0), seed=1, sharding=args.sharding, want_rgb8=False)
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        r.render(sppx=min(args.sppx, 4), **kwr)
+    rays, ms_trace, ms_reduce = 0, 0.0, 0.0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fb, _, st = r.render(sppx=args.sppx, **kwr)
+        rays += st["rays"]
+        ms_trace += st["ms_trace"]
+        ms_reduce += st["ms_reduce"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    assert (fb[:, 3] == args.sppx).all(), "the combined frame does not hold every sample of every pixel"
+    stats = torch.tensor([elapsed, float(rays), ms_reduce], dtype=torch.float64, device=dev)
+    total_rays = float(rays)
+    if world > 1:
+        mx = stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = stats.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed, total_rays, ms_reduce = float(mx[0].item()), float(sm[1].item()), float(mx[2].item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "Mrays/sec (path-traced frame: closest-hit and any-hit rays, framebuffer all-reduce included)",
+            "value": round(total_rays / elapsed / 1e6, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload.replace("_bounce", "") + "_frame", "triangles": int(len(tri)),
+                       "bvh": ("%s %s" % (args.layout, args.bvh or "om")).strip(), "resolution": "%dx%d" % (args.width, args.height),
+                       "sppx": args.sppx, "bounces": args.bounces, "sharding": "%s dealt over the GPUs, BVH replicated" % args.sharding,
+                       "rays_per_frame": int(total_rays / args.steps), "bvh_build_s": round(build_s, 2)},
+            "framebuffer_exchange": {"how": "one ncclAllReduce of w*h float4 (sums and counts) per frame, called from C++",
+                                     "bytes": args.width * args.height * 16, "ms_per_frame_max_over_ranks": round(ms_reduce / args.steps, 3),
+                                     "used_rccl": int(st["used_rccl"])},
+            "mean_radiance": [round(float(v), 6) for v in fb[:, 0:3].mean(0)],
+        }), flush=True)
+    r.close()
 
 
 def roofline(workload, total_bytes, n, kernel_ms, alg, lane_rate, miss_rate, rate_source):

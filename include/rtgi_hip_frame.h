@@ -66,6 +66,14 @@ typedef struct rtgi_frame_stats {
  * on that GPU instead of RCCL, which refuses two ranks on one GPU. Returns NULL on failure
  * (rtgi_hip_renderer_last_error(NULL) has the text). */
 rtgi_hip_renderer *rtgi_hip_renderer_create(const int *devices, int n, int layout, int esc);
+/* The same tracer with one process per GPU (the launch of `torch.distributed.run`, MPI and the like): every process
+ * creates the renderer of its own GPU as rank `rank` of `world`. The ranks find each other through a 128-byte id
+ * that one process gets from rtgi_hip_renderer_unique_id and hands to the others by whatever means the launcher has
+ * (a broadcast, a file); create_rank returns when all `world` processes have called it (ncclCommInitRank). render()
+ * is then a collective call: every rank calls it with the same frame, renders its tiles (or samples), and receives
+ * the whole frame through one ncclAllReduce; stats->rays counts this rank's rays only. */
+int rtgi_hip_renderer_unique_id(void *out, size_t bytes);
+rtgi_hip_renderer *rtgi_hip_renderer_create_rank(int device, int layout, int esc, int rank, int world, const void *unique_id);
 void rtgi_hip_renderer_destroy(rtgi_hip_renderer *r);
 int rtgi_hip_renderer_device_count(const rtgi_hip_renderer *r);
 /* The i-th GPU's tracer handle, e.g. for the read-back calls of rtgi_hip.h (owned by the renderer). */

@@ -56,6 +56,8 @@ struct rtgi_hip_renderer {
 	std::vector<Part> parts;
 	bool distinct = true;  // every part on a GPU of its own: RCCL combines the framebuffers
 	bool comms_ready = false;
+	// one process per GPU: this renderer is rank world_rank of world_size processes (0: all parts live in this process)
+	int world_rank = 0, world_size = 0;
 	std::string error;
 };
 
@@ -303,6 +305,43 @@ rtgi_hip_renderer *rtgi_hip_renderer_create(const int *devices, int n, int layou
 	return r;
 }
 
+int rtgi_hip_renderer_unique_id(void *out, size_t bytes) {
+	if (!out || bytes < sizeof(ncclUniqueId)) return RTGI_ERR_INVALID;
+	ncclUniqueId id;
+	const ncclResult_t e = ncclGetUniqueId(&id);
+	if (e != ncclSuccess) {
+		g_create_error = std::string("ncclGetUniqueId: ") + ncclGetErrorString(e);
+		return RTGI_ERR_DEVICE;
+	}
+	std::memset(out, 0, bytes);
+	std::memcpy(out, &id, sizeof(id));
+	return RTGI_OK;
+}
+
+rtgi_hip_renderer *rtgi_hip_renderer_create_rank(int device, int layout, int esc, int rank, int world, const void *unique_id) {
+	if (world < 1 || rank < 0 || rank >= world || !unique_id) {
+		g_create_error = "renderer_create_rank: rank must be in [0, world) and the id of rtgi_hip_renderer_unique_id given";
+		return nullptr;
+	}
+	rtgi_hip_renderer *r = rtgi_hip_renderer_create(&device, 1, layout, esc);
+	if (!r) return nullptr;
+	r->world_rank = rank;
+	r->world_size = world;
+	ncclUniqueId id;
+	std::memcpy(&id, unique_id, sizeof(id));
+	Part &p = r->parts[0];
+	hipError_t he = hipSetDevice(p.device);
+	const ncclResult_t e = he == hipSuccess ? ncclCommInitRank(&p.comm, world, id, rank) : ncclUnhandledCudaError;
+	if (e != ncclSuccess) {
+		g_create_error = std::string("ncclCommInitRank: ") + ncclGetErrorString(e);
+		p.comm = nullptr;
+		rtgi_hip_renderer_destroy(r);
+		return nullptr;
+	}
+	r->comms_ready = true;
+	return r;
+}
+
 void rtgi_hip_renderer_destroy(rtgi_hip_renderer *r) {
 	if (!r) return;
 	for (Part &p : r->parts) {
@@ -353,11 +392,12 @@ int rtgi_hip_renderer_render(rtgi_hip_renderer *r, const rtgi_frame *frame, floa
 	if (!r) return RTGI_ERR_INVALID;
 	if (int rc = check_frame(r, frame)) return rc;
 	const rtgi_frame f = *frame;
-	const int world = (int)r->parts.size();
+	const bool by_rank = r->world_size > 0;
+	const int world = by_rank ? r->world_size : (int)r->parts.size();
 	const uint32_t n_full = (uint32_t)f.cam.w * (uint32_t)f.cam.h;
 	const double t0 = now_ms();
 	// communicators for the framebuffer exchange, once: one rank per GPU, all in this process
-	if (world > 1 && r->distinct && !r->comms_ready) {
+	if (!by_rank && world > 1 && r->distinct && !r->comms_ready) {
 		std::vector<ncclComm_t> comms((size_t)world);
 		std::vector<int> devs((size_t)world);
 		for (int i = 0; i < world; ++i) devs[(size_t)i] = r->parts[(size_t)i].device;
@@ -366,14 +406,14 @@ int rtgi_hip_renderer_render(rtgi_hip_renderer *r, const rtgi_frame *frame, floa
 		for (int i = 0; i < world; ++i) r->parts[(size_t)i].comm = comms[(size_t)i];
 		r->comms_ready = true;
 	}
-	int rc = for_each_part(r, [&](int i) { render_part(r->parts[(size_t)i], f, i, world); });
+	int rc = for_each_part(r, [&](int i) { render_part(r->parts[(size_t)i], f, by_rank ? r->world_rank : i, world); });
 	if (rc) return rc;
 	double t_traced = t0;
 	for (const Part &p : r->parts) t_traced = std::max(t_traced, p.t_traced);
 	// ---- the one exchange of a frame: framebuffers as sums and counts (tiles: every pixel has one owner, the
 	// others hold zeros, and x + 0 = x keeps the owner's value to the bit) ----
 	bool used_rccl = false;
-	if (world > 1) {
+	if (world > 1 || by_rank) {
 		if (r->distinct) {
 			rc = for_each_part(r, [&](int i) {
 				Part &p = r->parts[(size_t)i];
@@ -400,7 +440,7 @@ int rtgi_hip_renderer_render(rtgi_hip_renderer *r, const rtgi_frame *frame, floa
 				if (arc < 0) return fail(r, arc, rtgi_hip_last_error(p0.h));
 			}
 		}
-		if (f.sharding == RTGI_SHARD_SAMPLES) {
+		if (world > 1 && f.sharding == RTGI_SHARD_SAMPLES) {
 			const int src = rtgi_hip_framebuffer_sums_device(r->parts[0].h, r->parts[0].d_full, n_full, 0, r->parts[0].stream);
 			if (src < 0) return fail(r, src, rtgi_hip_last_error(r->parts[0].h));
 		}
@@ -420,7 +460,7 @@ int rtgi_hip_renderer_render(rtgi_hip_renderer *r, const rtgi_frame *frame, floa
 	if (stats) {
 		stats->ms_total = now_ms() - t0;
 		stats->ms_trace = t_traced - t0;
-		stats->ms_reduce = world > 1 ? t_reduced - t_traced : 0.0;
+		stats->ms_reduce = (world > 1 || by_rank) ? t_reduced - t_traced : 0.0;
 		stats->rays = 0;
 		for (const Part &p : r->parts) stats->rays += p.rays;
 		stats->n_devices = world;

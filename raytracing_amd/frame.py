@@ -20,7 +20,7 @@ SHARDING = {"tiles": 0, "samples": 1}
 
 # every symbol include/rtgi_hip_frame.h declares
 EXPORTS = [
-    "rtgi_hip_renderer_create", "rtgi_hip_renderer_destroy", "rtgi_hip_renderer_device_count", "rtgi_hip_renderer_handle",
+    "rtgi_hip_renderer_create", "rtgi_hip_renderer_unique_id", "rtgi_hip_renderer_create_rank", "rtgi_hip_renderer_destroy", "rtgi_hip_renderer_device_count", "rtgi_hip_renderer_handle",
     "rtgi_hip_renderer_interprete", "rtgi_hip_renderer_build", "rtgi_hip_renderer_render", "rtgi_hip_renderer_last_error",
 ]
 
@@ -54,6 +54,9 @@ def lib():
         vp, i32, u32, sz, cp = C.c_void_p, C.c_int, C.c_uint32, C.c_size_t, C.c_char_p
         L.rtgi_hip_renderer_create.argtypes = [C.POINTER(C.c_int), i32, i32, i32]
         L.rtgi_hip_renderer_create.restype = vp
+        L.rtgi_hip_renderer_unique_id.argtypes = [vp, sz]
+        L.rtgi_hip_renderer_create_rank.argtypes = [i32, i32, i32, i32, i32, vp]
+        L.rtgi_hip_renderer_create_rank.restype = vp
         L.rtgi_hip_renderer_destroy.argtypes = [vp]
         L.rtgi_hip_renderer_destroy.restype = None
         L.rtgi_hip_renderer_device_count.argtypes = [vp]
@@ -71,12 +74,25 @@ def lib():
 class HipRenderer:
     """`raytracer hip [indexed] [esc] devices N` with the frame loop of `run` on the GPUs."""
 
-    def __init__(self, devices=(0,), layout="flat", esc=False):
-        devs = (C.c_int * len(devices))(*devices)
-        self._r = lib().rtgi_hip_renderer_create(devs, len(devices), tracer.LAYOUT[layout], int(esc))
+    def __init__(self, devices=(0,), layout="flat", esc=False, rank=None, world=None, unique_id=None):
+        """devices: the GPUs of this process. With rank/world/unique_id (one process per GPU): this process's GPU is
+        devices[0], unique_id the bytes of unique_id() as handed out by one of the processes."""
+        if rank is None:
+            devs = (C.c_int * len(devices))(*devices)
+            self._r = lib().rtgi_hip_renderer_create(devs, len(devices), tracer.LAYOUT[layout], int(esc))
+        else:
+            buf = C.create_string_buffer(bytes(unique_id), 128)
+            self._r = lib().rtgi_hip_renderer_create_rank(devices[0], tracer.LAYOUT[layout], int(esc), rank, world, buf)
         if not self._r:
             raise tracer.RtgiHipError(lib().rtgi_hip_renderer_last_error(None).decode())
         self.devices = tuple(devices)
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        if lib().rtgi_hip_renderer_unique_id(buf, 128) < 0:
+            raise tracer.RtgiHipError(lib().rtgi_hip_renderer_last_error(None).decode())
+        return buf.raw
 
     def close(self):
         if getattr(self, "_r", None):

@@ -129,6 +129,20 @@ def test_samples_over_several_handles():
     assert st["rays"] == 2 * w * h * spp
 
 
+def test_one_process_per_gpu_form_goes_through_rccl():
+    """rank 0 of a world of 1: the frame is that of the plain renderer, and the framebuffer did pass through
+    ncclAllReduce (the call every rank makes when there are several)."""
+    s = _scene()
+    kw = dict(fovy=65.0, w=160, h=90, sppx=2, algo="local", light_pos=LIGHT_POS, light_col=LIGHT_COL, seed=3, **CAM)
+    one, _, _ = _renderer(s).render(**kw)
+    r = frame.HipRenderer(devices=(0,), rank=0, world=1, unique_id=frame.HipRenderer.unique_id())
+    r.build(s["pos"], s["normals"], s["tri"], s["material_id"], s["albedo"])
+    for sharding in ("tiles", "samples"):
+        fb, _, st = r.render(sharding=sharding, **kw)
+        assert st["used_rccl"] == 1 and st["n_devices"] == 1
+        assert np.array_equal(fb.view(np.uint32), one.view(np.uint32))
+
+
 def test_frame_argument_checks():
     from raytracing_amd import tracer
     s = _scene()
