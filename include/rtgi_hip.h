@@ -230,6 +230,28 @@ int rtgi_hip_shade_primary_device(rtgi_hip_tracer *h, const rtgi_hit *d_hits, ui
 int rtgi_hip_shade_local_device(rtgi_hip_tracer *h, const rtgi_hit *d_hits, const uint8_t *d_occluded, uint32_t n,
                                 const float light_pos[3], const float light_col[3], float *d_radiance, void *stream);
 
+/* struct material, libgi/material.h:54-61, as far as local illumination reads it, and the brdf names of new_brdf
+ * (libgi/material.cpp:77-102: "lambert", "phong", "layered-phong", "gtr2", "layered-gtr2"). Albedo textures are not
+ * supported (`material texture drop` is the state every material is in). */
+enum { RTGI_BRDF_LAMBERT = 0, RTGI_BRDF_PHONG = 1, RTGI_BRDF_LAYERED_PHONG = 2, RTGI_BRDF_GTR2 = 3, RTGI_BRDF_LAYERED_GTR2 = 4 };
+typedef struct rtgi_material {
+	float albedo[3];
+	float ior;       /* default 1.3 */
+	float roughness; /* default 0.1 */
+	uint32_t brdf;   /* RTGI_BRDF_* */
+} rtgi_material;
+
+/* `material albedo | ior | roughness | brdf ...` and `default-brdf` (driver/interaction.cpp:250-341): replaces the
+ * material table given to rtgi_hip_set_shading (which sets ior 1.3, roughness 0.1, lambert), same number of
+ * materials. Waits for the GPU; no rebuild needed. */
+int rtgi_hip_set_materials(rtgi_hip_tracer *h, const rtgi_material *materials, uint32_t n_materials);
+
+/* rtgi_hip_shade_local_device with the BRDF of each hit's material (brdf::f, libgi/material.cpp:7-75): needs the
+ * rays the hits belong to, for w_o = -ray.d (gi/primary-hit.cpp:45). For lambertian materials the result is
+ * bit-identical to rtgi_hip_shade_local_device. */
+int rtgi_hip_shade_local_brdf_device(rtgi_hip_tracer *h, const rtgi_ray *d_rays, const rtgi_hit *d_hits, const uint8_t *d_occluded,
+                                     uint32_t n, const float light_pos[3], const float light_col[3], float *d_radiance, void *stream);
+
 /* framebuffer::add, libgi/framebuffer.cpp:10-18, one sample for each of n pixels: d_framebuffer is n x float4
  * (running mean rgb, sample count in w), zero-filled by the caller like framebuffer::clear. */
 int rtgi_hip_framebuffer_add_device(rtgi_hip_tracer *h, float *d_framebuffer, const float *d_radiance, uint32_t n, void *stream);

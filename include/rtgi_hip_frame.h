@@ -89,6 +89,10 @@ int rtgi_hip_renderer_build(rtgi_hip_renderer *r, const void *vertices, size_t v
                             const void *triangles, size_t tri_stride, uint32_t n_triangles, const float *albedo_rgb,
                             uint32_t n_materials);
 
+/* `material ...` / `default-brdf` after `commit` (driver/interaction.cpp:250-341): rtgi_hip_set_materials on every
+ * GPU. The frames' shading is brdf::f of each hit's material (libgi/material.cpp:7-75). */
+int rtgi_hip_renderer_set_materials(rtgi_hip_renderer *r, const rtgi_material *materials, uint32_t n_materials);
+
 /* `run`. framebuffer: w*h float4 (mean rgb, sample count) like rc->framebuffer.color, or NULL; rgb8: 3*w*h bytes like
  * framebuffer::png (top row first), or NULL; stats: or NULL. */
 int rtgi_hip_renderer_render(rtgi_hip_renderer *r, const rtgi_frame *frame, float *framebuffer, uint8_t *rgb8,

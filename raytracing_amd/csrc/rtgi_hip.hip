@@ -163,6 +163,7 @@ struct rtgi_hip_tracer {
 	float4 *d_corners = nullptr;  // triangle corners by reported id
 	float4 *d_normals = nullptr;  // shading normal and material index by reported id (set_shading)
 	float4 *d_albedo = nullptr;
+	float4 *d_matparams = nullptr;  // per material: ior, roughness, brdf kind (set_shading: 1.3, 0.1, lambert; set_materials)
 	uint32_t n_materials = 0, n_scene_triangles = 0, n_scene_vertices = 0;
 	// Launches that use the handle's scratch (ray counters, sort buffers, spill area, block counts) are ordered on
 	// the GPU even when the caller moves from one stream to another: see scratch_begin / scratch_end.
@@ -253,7 +254,8 @@ void free_device_tree(rtgi_hip_tracer *h) {
 	if (h->d_corners) (void)hipFree(h->d_corners);
 	if (h->d_normals) (void)hipFree(h->d_normals);
 	if (h->d_albedo) (void)hipFree(h->d_albedo);
-	h->d_corners = h->d_normals = h->d_albedo = nullptr;
+	if (h->d_matparams) (void)hipFree(h->d_matparams);
+	h->d_corners = h->d_normals = h->d_albedo = h->d_matparams = nullptr;
 	h->n_materials = 0;
 	h->d_nodes = h->d_tris = nullptr;
 	h->d_spill = nullptr;
@@ -1377,18 +1379,46 @@ int rtgi_hip_set_shading(rtgi_hip_tracer *h, const void *vertex_normals, size_t 
 	HIP_TRY(h, device_scope.status);
 	if (h->d_normals) (void)hipFree(h->d_normals);
 	if (h->d_albedo) (void)hipFree(h->d_albedo);
-	h->d_normals = h->d_albedo = nullptr;
+	if (h->d_matparams) (void)hipFree(h->d_matparams);
+	h->d_normals = h->d_albedo = h->d_matparams = nullptr;
 	h->n_materials = 0;
+	// (material defaults of libgi/material.h:58-59: ior 1.3, roughness 0.1; brdf lambert, libgi/scene.cpp:100-102)
+	std::vector<float> params((size_t)n_materials * 4, 0.0f);
+	for (uint32_t m = 0; m < n_materials; ++m) params[(size_t)m * 4] = 1.3f, params[(size_t)m * 4 + 1] = 0.1f;
 	HIP_TRY(h, hipMalloc((void **)&h->d_normals, std::max<size_t>(normals.size() * sizeof(float), 16)));
 	HIP_TRY(h, hipMalloc((void **)&h->d_albedo, albedo.size() * sizeof(float)));
+	HIP_TRY(h, hipMalloc((void **)&h->d_matparams, params.size() * sizeof(float)));
 	if (!normals.empty()) HIP_TRY(h, hipMemcpy(h->d_normals, normals.data(), normals.size() * sizeof(float), hipMemcpyHostToDevice));
 	HIP_TRY(h, hipMemcpy(h->d_albedo, albedo.data(), albedo.size() * sizeof(float), hipMemcpyHostToDevice));
+	HIP_TRY(h, hipMemcpy(h->d_matparams, params.data(), params.size() * sizeof(float), hipMemcpyHostToDevice));
 	h->n_materials = n_materials;
 	return RTGI_OK;
 }
 
+int rtgi_hip_set_materials(rtgi_hip_tracer *h, const rtgi_material *materials, uint32_t n_materials) {
+	if (!h) return RTGI_ERR_INVALID;
+	if (h->device < 0) return fail(h, RTGI_ERR_DEVICE, "host-only handle: needs a GPU");
+	if (!h->n_materials) return fail(h, RTGI_ERR_NOT_BUILT, "no shading data: call set_shading after build");
+	if (!materials || n_materials != h->n_materials) return fail(h, RTGI_ERR_INVALID, "set_materials: as many materials as set_shading was given");
+	std::vector<float> albedo((size_t)n_materials * 4, 0.0f), params((size_t)n_materials * 4, 0.0f);
+	for (uint32_t m = 0; m < n_materials; ++m) {
+		if (materials[m].brdf > RTGI_BRDF_LAYERED_GTR2) return fail(h, RTGI_ERR_INVALID, "set_materials: no such brdf");
+		for (int k = 0; k < 3; ++k) albedo[(size_t)m * 4 + k] = materials[m].albedo[k];
+		params[(size_t)m * 4] = materials[m].ior;
+		params[(size_t)m * 4 + 1] = materials[m].roughness;
+		memcpy(&params[(size_t)m * 4 + 2], &materials[m].brdf, 4);
+	}
+	DeviceScope device_scope(h->device);
+	HIP_TRY(h, device_scope.status);
+	// (stream-ordered behind whatever still shades with the old values on the null stream's peers: wait for the GPU)
+	HIP_TRY(h, hipDeviceSynchronize());
+	HIP_TRY(h, hipMemcpy(h->d_albedo, albedo.data(), albedo.size() * sizeof(float), hipMemcpyHostToDevice));
+	HIP_TRY(h, hipMemcpy(h->d_matparams, params.data(), params.size() * sizeof(float), hipMemcpyHostToDevice));
+	return RTGI_OK;
+}
+
 namespace {
-int shade(rtgi_hip_tracer *h, bool local, const rtgi_hit *d_hits, const uint8_t *d_occluded, uint32_t n, const float *light_pos,
+int shade(rtgi_hip_tracer *h, bool local, const rtgi_ray *d_rays, const rtgi_hit *d_hits, const uint8_t *d_occluded, uint32_t n, const float *light_pos,
           const float *light_col, float *d_radiance, void *stream) {
 	if (!h) return RTGI_ERR_INVALID;
 	if (h->device < 0) return fail(h, RTGI_ERR_DEVICE, "host-only handle: needs a GPU");
@@ -1398,6 +1428,7 @@ int shade(rtgi_hip_tracer *h, bool local, const rtgi_hit *d_hits, const uint8_t 
 	if (!d_hits || !d_radiance || ((reinterpret_cast<uintptr_t>(d_hits) | reinterpret_cast<uintptr_t>(d_radiance)) & 15u))
 		return fail(h, RTGI_ERR_INVALID, "shade: null or misaligned buffer");
 	if (local && (!d_occluded || !light_pos || !light_col)) return fail(h, RTGI_ERR_INVALID, "shade_local: null argument");
+	if (d_rays && (reinterpret_cast<uintptr_t>(d_rays) & 15u)) return fail(h, RTGI_ERR_INVALID, "shade: misaligned ray buffer");
 	DeviceScope device_scope(h->device);
 	HIP_TRY(h, device_scope.status);
 	rtgi_dev::ShadeArgs a;
@@ -1414,7 +1445,11 @@ int shade(rtgi_hip_tracer *h, bool local, const rtgi_hit *d_hits, const uint8_t 
 	}
 	a.n = n;
 	a.n_materials = h->n_materials;
-	if (local)
+	a.rays = (const float4 *)d_rays;
+	a.params = h->d_matparams;
+	if (local && d_rays)
+		hipLaunchKernelGGL(rtgi_dev::shade_local_brdf_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+	else if (local)
 		hipLaunchKernelGGL(rtgi_dev::shade_local_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
 	else
 		hipLaunchKernelGGL(rtgi_dev::shade_primary_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
@@ -1424,12 +1459,18 @@ int shade(rtgi_hip_tracer *h, bool local, const rtgi_hit *d_hits, const uint8_t 
 }  // namespace
 
 int rtgi_hip_shade_primary_device(rtgi_hip_tracer *h, const rtgi_hit *d_hits, uint32_t n, float *d_radiance, void *stream) {
-	return shade(h, false, d_hits, nullptr, n, nullptr, nullptr, d_radiance, stream);
+	return shade(h, false, nullptr, d_hits, nullptr, n, nullptr, nullptr, d_radiance, stream);
 }
 
 int rtgi_hip_shade_local_device(rtgi_hip_tracer *h, const rtgi_hit *d_hits, const uint8_t *d_occluded, uint32_t n,
                                 const float light_pos[3], const float light_col[3], float *d_radiance, void *stream) {
-	return shade(h, true, d_hits, d_occluded, n, light_pos, light_col, d_radiance, stream);
+	return shade(h, true, nullptr, d_hits, d_occluded, n, light_pos, light_col, d_radiance, stream);
+}
+
+int rtgi_hip_shade_local_brdf_device(rtgi_hip_tracer *h, const rtgi_ray *d_rays, const rtgi_hit *d_hits, const uint8_t *d_occluded,
+                                     uint32_t n, const float light_pos[3], const float light_col[3], float *d_radiance, void *stream) {
+	if (h && n && !d_rays) return fail(h, RTGI_ERR_INVALID, "shade_local_brdf: null ray buffer");
+	return shade(h, true, d_rays, d_hits, d_occluded, n, light_pos, light_col, d_radiance, stream);
 }
 
 int rtgi_hip_framebuffer_add_device(rtgi_hip_tracer *h, float *d_framebuffer, const float *d_radiance, uint32_t n, void *stream) {

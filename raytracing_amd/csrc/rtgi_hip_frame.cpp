@@ -184,7 +184,7 @@ int render_part(Part &p, const rtgi_frame &f, int rank, int world) {
 			PART_RT(p, rtgi_hip_shadow_rays_device(p.h, p.d_hits, n, f.light_pos, p.d_shadow, st));
 			PART_RT(p, rtgi_hip_any_hit_device(p.h, p.d_shadow, n, p.d_occluded, nullptr, st));
 			p.rays += n;
-			PART_RT(p, rtgi_hip_shade_local_device(p.h, p.d_hits, p.d_occluded, n, f.light_pos, f.light_col, p.d_radiance, st));
+			PART_RT(p, rtgi_hip_shade_local_brdf_device(p.h, p.d_rays[0], p.d_hits, p.d_occluded, n, f.light_pos, f.light_col, p.d_radiance, st));
 		} else {
 			// a path per pixel sample: light every vertex, then follow one diffuse bounce, `bounces` times
 			PART_RT(p, rtgi_hip_path_begin_device(p.h, n, p.d_throughput[0], p.d_slot[0], p.d_radiance, st));
@@ -198,7 +198,7 @@ int render_part(Part &p, const rtgi_frame &f, int rank, int world) {
 				PART_RT(p, rtgi_hip_shadow_rays_device(p.h, p.d_hits, m, f.light_pos, p.d_shadow, st));
 				PART_RT(p, rtgi_hip_any_hit_device(p.h, p.d_shadow, m, p.d_occluded, nullptr, st));
 				p.rays += m;
-				PART_RT(p, rtgi_hip_shade_local_device(p.h, p.d_hits, p.d_occluded, m, f.light_pos, f.light_col, p.d_direct, st));
+				PART_RT(p, rtgi_hip_shade_local_brdf_device(p.h, p.d_rays[cur], p.d_hits, p.d_occluded, m, f.light_pos, f.light_col, p.d_direct, st));
 				PART_RT(p, rtgi_hip_path_add_device(p.h, p.d_direct, p.d_throughput[cur], p.d_slot[cur], m, p.d_radiance, st));
 				if (depth == f.bounces) break;
 				PART_RT(p, rtgi_hip_shade_primary_device(p.h, p.d_hits, m, p.d_albedo, st));
@@ -386,6 +386,15 @@ int rtgi_hip_renderer_build(rtgi_hip_renderer *r, const void *vertices, size_t v
 			                          n_materials);
 		if (rc < 0) fail(p, rc, rtgi_hip_last_error(p.h));
 	});
+}
+
+int rtgi_hip_renderer_set_materials(rtgi_hip_renderer *r, const rtgi_material *materials, uint32_t n_materials) {
+	if (!r) return RTGI_ERR_INVALID;
+	for (Part &p : r->parts) {
+		const int rc = rtgi_hip_set_materials(p.h, materials, n_materials);
+		if (rc < 0) return fail(r, rc, rtgi_hip_last_error(p.h));
+	}
+	return RTGI_OK;
 }
 
 int rtgi_hip_renderer_render(rtgi_hip_renderer *r, const rtgi_frame *frame, float *framebuffer, uint8_t *rgb8, rtgi_frame_stats *stats) {

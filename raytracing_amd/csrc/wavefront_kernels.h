@@ -230,6 +230,8 @@ struct ShadeArgs {
 	float4 *out;              // radiance rgb, w = 0
 	float light[3], power[3];
 	uint32_t n, n_materials;
+	const float4 *rays;       // shade_local_brdf: the rays whose hits are shaded (w_o = -d)
+	const float4 *params;     // shade_local_brdf: per material ior, roughness, brdf kind (bits)
 };
 
 __device__ __forceinline__ float4 material_albedo(const ShadeArgs &a, float4 normal) {
@@ -278,6 +280,140 @@ __global__ __launch_bounds__(256) void shade_local_kernel(ShadeArgs a) {
 			c.y = a.power[1] * (one_over_pi * alb.y) / dd;
 			c.z = a.power[2] * (one_over_pi * alb.z) / dd;
 		}
+	}
+	a.out[i] = c;
+}
+
+// ---- the renderer's other BRDFs (libgi/material.cpp:7-75), evaluated like the reference does: same operations in
+// the same order, so that everything but powf is bit-identical to a host evaluation ----
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) { return ax * bx + ay * by + az * bz; }
+__device__ __forceinline__ float cdot3(float ax, float ay, float az, float bx, float by, float bz) {  // libgi/util.h:12-15
+	const float x = ax * bx + ay * by + az * bz;
+	return x < 0.0f ? 0.0f : x;
+}
+// fresnel_dielectric, libgi/util.h:44-60
+__device__ __forceinline__ float fresnel_dielectric(float cos_wi, float ior_medium, float ior_material) {
+	const float ei = cos_wi < 0.0f ? ior_material : ior_medium;
+	const float et = cos_wi < 0.0f ? ior_medium : ior_material;
+	cos_wi = fminf(fmaxf(fabsf(cos_wi), 0.0f), 1.0f);
+	const float sin_t = (ei / et) * sqrtf(1.0f - cos_wi * cos_wi);
+	if (sin_t >= 1.0f) return 1.0f;
+	const float rev_sin2 = 1.0f - sin_t * sin_t;
+	const float cos_t = sqrtf(rev_sin2 > 0.0f ? rev_sin2 : 0.0f);
+	const float Rparl = ((et * cos_wi) - (ei * cos_t)) / ((et * cos_wi) + (ei * cos_t));
+	const float Rperp = ((ei * cos_wi) - (et * cos_t)) / ((ei * cos_wi) + (et * cos_t));
+	return (Rparl * Rparl + Rperp * Rperp) / 2;
+}
+__device__ __forceinline__ float tan2_theta(float c) {  // libgi/util.h:73-87
+	const float res = 1.0f - c * c;
+	return (res < 0.0f ? 0.0f : res) / (c * c);
+}
+__device__ __forceinline__ float ggx_d(float NdotH, float roughness) {  // libgi/material.cpp:40-46
+	if (NdotH <= 0) return 0.f;
+	const float tan2 = tan2_theta(NdotH);
+	if (!isfinite(tan2)) return 0.f;
+	const float a2 = roughness * roughness;
+	const float pi = (float)3.14159265358979323846;
+	const float n2 = NdotH * NdotH, s = a2 + tan2;
+	return a2 / (pi * (n2 * n2) * (s * s));
+}
+__device__ __forceinline__ float ggx_g1(float NdotV, float roughness) {  // libgi/material.cpp:48-53
+	if (NdotV <= 0) return 0.f;
+	const float tan2 = tan2_theta(NdotV);
+	if (!isfinite(tan2)) return 0.f;
+	return 2.f / (1.f + sqrtf(1.f + (roughness * roughness) * tan2));
+}
+
+enum { BRDF_LAMBERT = 0, BRDF_PHONG = 1, BRDF_LAYERED_PHONG = 2, BRDF_GTR2 = 3, BRDF_LAYERED_GTR2 = 4 };
+
+// lambertian_reflection::f, libgi/material.cpp:17-20
+__device__ __forceinline__ void brdf_lambert(float nx, float ny, float nz, float wix, float wiy, float wiz, float4 alb, float &r, float &g,
+                                             float &b) {
+	r = g = b = 0.0f;
+	if (!(dot3(nx, ny, nz, wix, wiy, wiz) > 0.0f)) return;  // same_hemisphere(w_i, ns): dot(w_i, ns), products commute
+	const float one_over_pi = (float)(1.0 / 3.14159265358979323846);
+	r = one_over_pi * alb.x, g = one_over_pi * alb.y, b = one_over_pi * alb.z;
+}
+// phong_specular_reflection::f, libgi/material.cpp:25-32 (ng = ns, libgi/rt.cpp:13)
+__device__ __forceinline__ void brdf_phong(float nx, float ny, float nz, float wox, float woy, float woz, float wix, float wiy, float wiz,
+                                           float4 alb, float roughness, bool coat, float &r, float &g, float &b) {
+	r = g = b = 0.0f;
+	if (!(dot3(wix, wiy, wiz, nx, ny, nz) > 0.0f)) return;
+	const float exponent = 2 / (roughness * roughness) - 2;  // exponent_from_roughness, libgi/material.h:15-17
+	const float d = dot3(wix, wiy, wiz, nx, ny, nz);
+	const float rx = 2.0f * nx * d - wix, ry = 2.0f * ny * d - wiy, rz = 2.0f * nz * d - wiz;
+	const float cos_theta = cdot3(wox, woy, woz, rx, ry, rz);
+	const float one_over_2pi = (float)(1.0 / (2 * 3.14159265358979323846));
+	const float norm_f = (exponent + 2.0f) * one_over_2pi;
+	const float p = powf(cos_theta, exponent), c = cdot3(wix, wiy, wiz, nx, ny, nz);
+	r = (coat ? 1.0f : alb.x) * p * norm_f * c;
+	g = (coat ? 1.0f : alb.y) * p * norm_f * c;
+	b = (coat ? 1.0f : alb.z) * p * norm_f * c;
+}
+// gtr2_reflection::f, libgi/material.cpp:58-73
+__device__ __forceinline__ void brdf_gtr2(float nx, float ny, float nz, float wox, float woy, float woz, float wix, float wiy, float wiz,
+                                          float4 alb, float roughness, float ior, bool coat, float &r, float &g, float &b) {
+	r = g = b = 0.0f;
+	if (!(dot3(nx, ny, nz, wix, wiy, wiz) > 0.0f)) return;
+	const float NdotV = cdot3(nx, ny, nz, wox, woy, woz);
+	const float NdotL = cdot3(nx, ny, nz, wix, wiy, wiz);
+	if (NdotV == 0.f) return;
+	const float hx = wox + wix, hy = woy + wiy, hz = woz + wiz;
+	const float inv = 1.0f / sqrtf(dot3(hx, hy, hz, hx, hy, hz));
+	const float Hx = hx * inv, Hy = hy * inv, Hz = hz * inv;
+	const float NdotH = cdot3(nx, ny, nz, Hx, Hy, Hz);
+	const float HdotL = cdot3(Hx, Hy, Hz, wix, wiy, wiz);
+	const float F = fresnel_dielectric(HdotL, 1.f, ior);
+	const float D = ggx_d(NdotH, roughness);
+	const float G = ggx_g1(NdotV, roughness) * ggx_g1(NdotL, roughness);
+	const float microfacet = (F * D * G) / (4 * fabsf(NdotV) * fabsf(NdotL));
+	r = coat ? microfacet : alb.x * microfacet;
+	g = coat ? microfacet : alb.y * microfacet;
+	b = coat ? microfacet : alb.z * microfacet;
+}
+
+// local_illumination::sample_pixel, gi/primary-hit.cpp:32-57, with the BRDF of the hit's material (lambert, phong,
+// gtr2, or one of the two under a lambertian base weighted by the Fresnel term: layered_brdf::f, libgi/material.cpp:7-12).
+__global__ __launch_bounds__(256) void shade_local_brdf_kernel(ShadeArgs a) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= a.n) return;
+	const float4 hit = a.hits[i];
+	float4 c = make_float4(0, 0, 0, 0);
+	if (hit.x != FLT_MAX && !a.occluded[i]) {
+		float x, y, z;
+		float4 A, B, C;
+		hit_point(a.corners, hit, x, y, z, A, B, C);
+		const float4 ns = a.normals[__float_as_uint(hit.w)];
+		const uint32_t m = __float_as_uint(ns.w);
+		const float4 alb = material_albedo(a, ns);
+		const float4 par = m < a.n_materials ? a.params[m] : make_float4(1.3f, 0.1f, 0.0f, 0.0f);
+		const uint32_t kind = __float_as_uint(par.z);
+		const float lx = a.light[0] - x, ly = a.light[1] - y, lz = a.light[2] - z;
+		const float d = sqrtf(dot3(lx, ly, lz, lx, ly, lz));
+		const float inv = 1.0f / d;
+		const float wix = lx * inv, wiy = ly * inv, wiz = lz * inv;
+		const float4 r0 = a.rays[2 * (size_t)i], r1 = a.rays[2 * (size_t)i + 1];
+		const float wox = -r0.w, woy = -r1.x, woz = -r1.y;
+		float fr, fg, fb;
+		if (kind == BRDF_LAMBERT)
+			brdf_lambert(ns.x, ns.y, ns.z, wix, wiy, wiz, alb, fr, fg, fb);
+		else if (kind == BRDF_PHONG)
+			brdf_phong(ns.x, ns.y, ns.z, wox, woy, woz, wix, wiy, wiz, alb, par.y, false, fr, fg, fb);
+		else if (kind == BRDF_GTR2)
+			brdf_gtr2(ns.x, ns.y, ns.z, wox, woy, woz, wix, wiy, wiz, alb, par.y, par.x, false, fr, fg, fb);
+		else {
+			float dr, dg, db, sr, sg, sb;
+			const float dn = dot3(ns.x, ns.y, ns.z, wox, woy, woz);
+			const float F = fresnel_dielectric(dn < 0.0f ? -dn : dn, 1.0f, par.x);  // absdot(ns, w_o)
+			brdf_lambert(ns.x, ns.y, ns.z, wix, wiy, wiz, alb, dr, dg, db);
+			if (kind == BRDF_LAYERED_PHONG)
+				brdf_phong(ns.x, ns.y, ns.z, wox, woy, woz, wix, wiy, wiz, alb, par.y, true, sr, sg, sb);
+			else
+				brdf_gtr2(ns.x, ns.y, ns.z, wox, woy, woz, wix, wiy, wiz, alb, par.y, par.x, true, sr, sg, sb);
+			fr = (1.0f - F) * dr + F * sr, fg = (1.0f - F) * dg + F * sg, fb = (1.0f - F) * db + F * sb;
+		}
+		const float dd = d * d;
+		c.x = a.power[0] * fr / dd, c.y = a.power[1] * fg / dd, c.z = a.power[2] * fb / dd;
 	}
 	a.out[i] = c;
 }

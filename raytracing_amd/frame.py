@@ -21,7 +21,7 @@ SHARDING = {"tiles": 0, "samples": 1}
 # every symbol include/rtgi_hip_frame.h declares
 EXPORTS = [
     "rtgi_hip_renderer_create", "rtgi_hip_renderer_unique_id", "rtgi_hip_renderer_create_rank", "rtgi_hip_renderer_destroy", "rtgi_hip_renderer_device_count", "rtgi_hip_renderer_handle",
-    "rtgi_hip_renderer_interprete", "rtgi_hip_renderer_build", "rtgi_hip_renderer_render", "rtgi_hip_renderer_last_error",
+    "rtgi_hip_renderer_interprete", "rtgi_hip_renderer_build", "rtgi_hip_renderer_set_materials", "rtgi_hip_renderer_render", "rtgi_hip_renderer_last_error",
 ]
 
 
@@ -64,6 +64,7 @@ def lib():
         L.rtgi_hip_renderer_handle.restype = vp
         L.rtgi_hip_renderer_interprete.argtypes = [vp, cp, cp]
         L.rtgi_hip_renderer_build.argtypes = [vp, vp, sz, u32, vp, sz, u32, vp, u32]
+        L.rtgi_hip_renderer_set_materials.argtypes = [vp, vp, u32]
         L.rtgi_hip_renderer_render.argtypes = [vp, C.POINTER(Frame), vp, vp, C.POINTER(FrameStats)]
         L.rtgi_hip_renderer_last_error.argtypes = [vp]
         L.rtgi_hip_renderer_last_error.restype = cp
@@ -120,6 +121,12 @@ class HipRenderer:
         albedo = np.ascontiguousarray(albedo, dtype=np.float32)
         self._check(lib().rtgi_hip_renderer_build(self._r, vertices.ctypes.data, 32, nv, tri4.ctypes.data, 16, nt,
                                                   albedo.ctypes.data, len(albedo)))
+
+    def set_materials(self, albedo, ior, roughness, brdf):
+        rec = np.zeros(len(albedo), tracer.MATERIAL_DTYPE)
+        rec["albedo"], rec["ior"], rec["roughness"] = albedo, ior, roughness
+        rec["brdf"] = [tracer.BRDF[b] for b in brdf]
+        self._check(lib().rtgi_hip_renderer_set_materials(self._r, rec.ctypes.data, len(rec)))
 
     def render(self, cam_dir, cam_pos, cam_up, fovy, w, h, sppx=1, algo="local", bounces=0, light_pos=(0, 0, 0),
                light_col=(1, 1, 1), seed=0, jitter=True, sharding="tiles", tile=0, want_rgb8=True):

@@ -17,6 +17,8 @@ HIT_DTYPE = np.dtype([("t", "<f4"), ("beta", "<f4"), ("gamma", "<f4"), ("ref", "
 NODE56_DTYPE = np.dtype([("box_l", "<f4", (6,)), ("box_r", "<f4", (6,)), ("link_l", "<i4"), ("link_r", "<i4")])
 assert RAY_DTYPE.itemsize == 32 and HIT_DTYPE.itemsize == 16 and NODE56_DTYPE.itemsize == 56
 
+MATERIAL_DTYPE = np.dtype([("albedo", "<f4", (3,)), ("ior", "<f4"), ("roughness", "<f4"), ("brdf", "<u4")])
+BRDF = {"lambert": 0, "phong": 1, "layered-phong": 2, "gtr2": 3, "layered-gtr2": 4}
 FLT_MAX = float(np.finfo(np.float32).max)
 LAYOUT = {"flat": 0, "indexed": 1}
 
@@ -31,7 +33,7 @@ EXPORTS = [
     "rtgi_hip_pixel_offsets_device", "rtgi_hip_pixel_offsets_pixels_device", "rtgi_hip_camera_rays_pixels_device",
     "rtgi_hip_bounce_rays_keyed_device", "rtgi_hip_path_begin_device", "rtgi_hip_path_add_device", "rtgi_hip_path_extend_device",
     "rtgi_hip_framebuffer_scatter_device", "rtgi_hip_framebuffer_sums_device", "rtgi_hip_framebuffer_accumulate_device", "rtgi_hip_shadow_rays_device", "rtgi_hip_bounce_rays_device", "rtgi_hip_set_shading",
-    "rtgi_hip_shade_primary_device", "rtgi_hip_shade_local_device", "rtgi_hip_framebuffer_add_device",
+    "rtgi_hip_shade_primary_device", "rtgi_hip_shade_local_device", "rtgi_hip_set_materials", "rtgi_hip_shade_local_brdf_device", "rtgi_hip_framebuffer_add_device",
     "rtgi_hip_framebuffer_rgb8_device", "rtgi_hip_profile_begin", "rtgi_hip_profile_end", "rtgi_hip_profile_work",
     "rtgi_hip_last_error",
 ]
@@ -100,6 +102,8 @@ def lib():
         L.rtgi_hip_set_shading.argtypes = [vp, vp, sz, u32, vp, sz, u32, vp, u32]
         L.rtgi_hip_shade_primary_device.argtypes = [vp, vp, u32, vp, vp]
         L.rtgi_hip_shade_local_device.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp]
+        L.rtgi_hip_set_materials.argtypes = [vp, vp, u32]
+        L.rtgi_hip_shade_local_brdf_device.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, vp]
         L.rtgi_hip_framebuffer_add_device.argtypes = [vp, vp, vp, u32, vp]
         L.rtgi_hip_framebuffer_rgb8_device.argtypes = [vp, vp, u32, u32, vp, vp]
         L.rtgi_hip_profile_begin.argtypes = [vp]
@@ -318,6 +322,24 @@ class HipBvhTracer:
         self._check(lib().rtgi_hip_shade_local_device(self._h, d_hits.data_ptr(), d_occluded.data_ptr(), d_hits.shape[0],
                                                       (C.c_float * 3)(*light_pos), (C.c_float * 3)(*light_col),
                                                       d_out.data_ptr(), self._stream(stream)))
+        return d_out
+
+    def set_materials(self, albedo, ior, roughness, brdf):
+        """Material table (libgi/material.h:54-61): albedo (n, 3), ior (n,), roughness (n,), brdf names (n,) out of
+        BRDF. Replaces what set_shading stored."""
+        n = len(albedo)
+        rec = np.zeros(n, MATERIAL_DTYPE)
+        rec["albedo"], rec["ior"], rec["roughness"] = albedo, ior, roughness
+        rec["brdf"] = [BRDF[b] for b in brdf]
+        self._check(lib().rtgi_hip_set_materials(self._h, rec.ctypes.data, n))
+
+    def shade_local_brdf_device(self, d_rays, d_hits, d_occluded, light_pos, light_col, stream=None):
+        """shade_local_device with each material's own BRDF (libgi/material.cpp:7-75); needs the rays for w_o."""
+        import torch
+        d_out = torch.empty((d_hits.shape[0], 4), dtype=torch.float32, device=d_hits.device)
+        self._check(lib().rtgi_hip_shade_local_brdf_device(self._h, d_rays.data_ptr(), d_hits.data_ptr(), d_occluded.data_ptr(),
+                                                           d_hits.shape[0], (C.c_float * 3)(*light_pos), (C.c_float * 3)(*light_col),
+                                                           d_out.data_ptr(), self._stream(stream)))
         return d_out
 
     def framebuffer_add_device(self, d_framebuffer, d_radiance, stream=None):

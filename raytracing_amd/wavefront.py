@@ -164,6 +164,123 @@ def shade_local(pos, tri, ns, material_id, albedo, hits, occluded, light_pos, li
     return out
 
 
+def _dot(a, b):
+    return ((a[:, 0] * b[:, 0] + a[:, 1] * b[:, 1]) + a[:, 2] * b[:, 2]).astype(np.float32)
+
+
+def _cdot(a, b):
+    x = _dot(a, b)
+    return np.where(x < 0, np.float32(0), x).astype(np.float32)
+
+
+def fresnel_dielectric(cos_wi, ior_medium, ior_material):
+    """libgi/util.h:44-60, float32, elementwise."""
+    f = np.float32
+    with np.errstate(all="ignore"):
+        ei = np.where(cos_wi < 0, ior_material, ior_medium).astype(f)
+        et = np.where(cos_wi < 0, ior_medium, ior_material).astype(f)
+        c = np.minimum(np.maximum(np.abs(cos_wi), f(0)), f(1)).astype(f)
+        sin_t = ((ei / et) * np.sqrt(f(1) - c * c, dtype=f)).astype(f)
+        rev = (f(1) - sin_t * sin_t).astype(f)
+        cos_t = np.sqrt(np.where(rev > 0, rev, f(0)).astype(f), dtype=f)
+        rparl = ((et * c) - (ei * cos_t)) / ((et * c) + (ei * cos_t))
+        rperp = ((ei * c) - (et * cos_t)) / ((ei * c) + (et * cos_t))
+        out = ((rparl * rparl + rperp * rperp) / f(2)).astype(f)
+    return np.where(sin_t >= 1, f(1), out).astype(f)
+
+
+def _tan2(c):
+    f = np.float32
+    with np.errstate(all="ignore"):
+        res = (f(1) - c * c).astype(f)
+        return (np.where(res < 0, f(0), res) / (c * c)).astype(f)
+
+
+def _ggx_d(n_h, roughness):
+    f = np.float32
+    with np.errstate(all="ignore"):
+        tan2 = _tan2(n_h)
+        a2 = (roughness * roughness).astype(f)
+        n2, s = (n_h * n_h).astype(f), (a2 + tan2).astype(f)
+        v = (a2 / ((PI * (n2 * n2)) * (s * s))).astype(f)
+    return np.where((n_h <= 0) | ~np.isfinite(tan2), f(0), v).astype(f)
+
+
+def _ggx_g1(n_v, roughness):
+    f = np.float32
+    with np.errstate(all="ignore"):
+        tan2 = _tan2(n_v)
+        v = (f(2) / (f(1) + np.sqrt(f(1) + (roughness * roughness) * tan2, dtype=f))).astype(f)
+    return np.where((n_v <= 0) | ~np.isfinite(tan2), f(0), v).astype(f)
+
+
+BRDF_NAMES = ("lambert", "phong", "layered-phong", "gtr2", "layered-gtr2")  # new_brdf, libgi/material.cpp:77-102
+
+
+def brdf_f(kind, n, w_o, w_i, alb, ior, roughness):
+    """brdf::f of libgi/material.cpp:7-75 for arrays of shading points (ng = ns, libgi/rt.cpp:13), float32 with the
+    reference's operation order; kind: index into BRDF_NAMES per point."""
+    f = np.float32
+    m = len(n)
+    facing = _dot(n, w_i) > 0
+    lam = np.where(facing[:, None], ONE_OVER_PI * alb, f(0)).astype(f)
+    with np.errstate(all="ignore"):
+        # phong (material.cpp:25-32)
+        exponent = (f(2) / (roughness * roughness) - f(2)).astype(f)
+        d = _dot(w_i, n)
+        r = ((f(2) * n) * d[:, None] - w_i).astype(f)
+        cos_theta = _cdot(w_o, r)
+        norm_f = ((exponent + f(2)) * np.float32(1.0 / (2 * np.pi))).astype(f)
+        p = np.power(cos_theta, exponent, dtype=f)
+        c = _cdot(w_i, n)
+
+        def phong(col):
+            return np.where(facing[:, None], ((col * p[:, None]) * norm_f[:, None]) * c[:, None], f(0)).astype(f)
+        # gtr2 (material.cpp:58-73)
+        n_v, n_l = _cdot(n, w_o), _cdot(n, w_i)
+        h = (w_o + w_i).astype(f)
+        H = (h * (f(1) / np.sqrt(_dot(h, h), dtype=f))[:, None]).astype(f)
+        n_h, h_l = _cdot(n, H), _cdot(H, w_i)
+        F = fresnel_dielectric(h_l, np.full(m, 1, f), ior)
+        D = _ggx_d(n_h, roughness)
+        G = (_ggx_g1(n_v, roughness) * _ggx_g1(n_l, roughness)).astype(f)
+        micro = (((F * D) * G) / ((f(4) * np.abs(n_v)) * np.abs(n_l))).astype(f)
+        micro = np.where(facing & (n_v != 0), micro, f(0)).astype(f)
+
+        def gtr2(coat):
+            return (np.repeat(micro[:, None], 3, 1) if coat else alb * micro[:, None]).astype(f)
+        one = np.ones((m, 3), f)
+        F_coat = fresnel_dielectric(np.abs(_dot(n, w_o)), np.full(m, 1, f), ior)[:, None]
+        variants = [lam, phong(alb), (f(1) - F_coat) * lam + F_coat * phong(one), gtr2(False),
+                    (f(1) - F_coat) * lam + F_coat * gtr2(True)]
+    out = np.zeros((m, 3), f)
+    for k, v in enumerate(variants):
+        sel = np.asarray(kind) == k
+        out[sel] = v[sel]
+    return out
+
+
+def shade_local_brdf(pos, tri, ns, material_id, materials, rays, hits, occluded, light_pos, light_col):
+    """shade_local with each hit material's own BRDF. materials: dict(albedo (n, 3), ior, roughness, kind); rays: the
+    (n, 8) rays of the hits (w_o = -d, gi/primary-hit.cpp:45)."""
+    f = np.float32
+    out = np.zeros((len(hits), 4), f)
+    lit = np.flatnonzero((hits["t"] != FLT_MAX) & (np.asarray(occluded) == 0))
+    hv = hits[lit]
+    x = hit_points(pos, tri, hv)
+    to_light = (np.asarray(light_pos, f)[None, :] - x).astype(f)
+    d = np.sqrt(_dot(to_light, to_light), dtype=f)
+    w_i = (to_light * (f(1.0) / d)[:, None]).astype(f)
+    w_o = (-np.asarray(rays, f)[lit, 3:6]).astype(f)
+    mid = np.asarray(material_id)[hv["ref"]]
+    fr = brdf_f(np.asarray(materials["kind"])[mid], ns[hv["ref"]], w_o, w_i, np.asarray(materials["albedo"], f)[mid],
+                np.asarray(materials["ior"], f)[mid], np.asarray(materials["roughness"], f)[mid])
+    power = (f(4) * PI) * np.asarray(light_col, f)
+    with np.errstate(all="ignore"):
+        out[lit, 0:3] = (power[None, :] * fr) / (d * d)[:, None]
+    return out
+
+
 def framebuffer_add(fb, radiance):
     """framebuffer::add, libgi/framebuffer.cpp:10-18, one sample per pixel: running mean in rgb, count in w."""
     f = np.float32

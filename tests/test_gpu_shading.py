@@ -106,6 +106,44 @@ def test_frame_of_the_brdf_test_script(layout, tmp_path):
     assert np.array_equal(png.read_rgb8(path), got)
 
 
+def test_brdfs_against_their_host_statement():
+    """Every BRDF of new_brdf (libgi/material.cpp:77-102) on the a3-brdf-test frame: lambert, gtr2 and layered-gtr2
+    bit-identical to the numpy statement of libgi/material.cpp; the two with phong within 1e-5 relative (powf)."""
+    import torch
+    s = _scene()
+    w, h = 400, 225
+    t = tracer.HipBvhTracer(layout="indexed")
+    t.build(s["pos"], s["tri"])
+    t.set_shading(s["normals"], s["tri"], s["material_id"], s["albedo"])
+    nm = len(s["albedo"])
+    rs = np.random.RandomState(5)
+    ns = wavefront.shading_normals(s["normals"], s["tri"])
+    d_rays = t.camera_rays_device(CAM["cam_dir"], CAM["cam_pos"], CAM["cam_up"], 65.0, w, h)
+    d_hits = torch.empty((w * h, 4), dtype=torch.float32, device="cuda")
+    t.closest_hit_device(d_rays, d_hits)
+    d_occ = torch.empty(w * h, dtype=torch.uint8, device="cuda")
+    t.any_hit_device(t.shadow_rays_device(d_hits, LIGHT_POS), d_occ)
+    rays, hits, occ = d_rays.cpu().numpy(), _hits_of(d_hits), d_occ.cpu().numpy()
+    lambert = t.shade_local_device(d_hits, d_occ, LIGHT_POS, LIGHT_COL).cpu().numpy()
+    assert np.array_equal(t.shade_local_brdf_device(d_rays, d_hits, d_occ, LIGHT_POS, LIGHT_COL).cpu().numpy().view(np.uint32),
+                          lambert.view(np.uint32))  # set_shading leaves every material lambertian
+    for kind, name in enumerate(wavefront.BRDF_NAMES):
+        mats = dict(albedo=s["albedo"], ior=rs.uniform(1.2, 2.6, nm).astype(np.float32),
+                    roughness=rs.uniform(0.02, 0.6, nm).astype(np.float32), kind=np.full(nm, kind))
+        t.set_materials(mats["albedo"], mats["ior"], mats["roughness"], [name] * nm)
+        got = t.shade_local_brdf_device(d_rays, d_hits, d_occ, LIGHT_POS, LIGHT_COL).cpu().numpy()
+        want = wavefront.shade_local_brdf(s["pos"], s["tri"], ns, s["material_id"], mats, rays, hits, occ, LIGHT_POS, LIGHT_COL)
+        assert np.isfinite(got).all() and (got[:, 0:3].sum(1) > 0).mean() > 0.05, name
+        if "phong" in name:
+            assert np.allclose(got, want, rtol=1e-5, atol=1e-30), name
+        else:
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), name
+        if name != "lambert":
+            assert not np.array_equal(got, lambert)
+    with pytest.raises(tracer.RtgiHipError):
+        t.set_materials(s["albedo"][:-1], np.ones(nm - 1), np.ones(nm - 1), ["lambert"] * (nm - 1))
+
+
 def test_shading_argument_checks():
     import torch
     s = _scene()
