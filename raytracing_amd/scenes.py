@@ -97,9 +97,9 @@ def load_obj_materials(path):
                     continue
                 if p[0] == "newmtl":
                     cur = names.index(p[1]) if p[1] in names else None
-                elif cur is not None and p[0] == "Kd":
+                elif cur is not None and p[0] in ("Kd", "kd"):
                     kd[cur] = [float(x) for x in p[1:4]]
-                elif cur is not None and p[0] == "Ks":
+                elif cur is not None and p[0] in ("Ks", "ks"):
                     ks[cur] = [float(x) for x in p[1:4]]
     return dict(pos=np.ascontiguousarray(pos), tri=tri, normals=np.ascontiguousarray(normals),
                 material_id=np.asarray(fmat, np.uint32), materials=names, kd=kd, ks=ks)
