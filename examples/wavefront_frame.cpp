@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "rtgi_hip.h"
+#include "rtgi_hip_tracer.hpp"  // hip_bvh_frame_tracer: the same frame through the renderer-side class
 
 struct vertex {  // libgi/rt.h:29-33
 	float pos[3], norm[3], tc[2];
@@ -138,6 +139,40 @@ int main(int argc, char **argv) {
 	for (size_t i = 0; i < rgb.size(); ++i) sum = sum * 1099511628211ull + rgb[i], lit += rgb[i] > 0;
 	printf("%dx%d, %d sppx, %zu triangles: %.2f ms on the GPU, %.0f Mrays/s; lit bytes %.1f%%; checksum %016llx; wrote %s\n", w, h, sppx,
 	       triangles.size(), ms, 2.0 * n * sppx / ms / 1e3, 100.0 * lit / rgb.size(), (unsigned long long)sum, out);
+	// The same frame through hip_bvh_frame_tracer, the object `raytracer hip` puts into scene.rt and the wavefront
+	// algorithms of rtgi_hip_algorithms.hpp render with: its framebuffer must be the stage-by-stage one, bit for bit.
+	std::vector<float> fb_stages((size_t)n * 4), fb_class((size_t)n * 4);
+	HIP_OK(hipMemcpy(fb_stages.data(), d_fb, fb_stages.size() * 4, hipMemcpyDeviceToHost));
+	int rc = 0;
+	try {
+		rtgi_hip::scene sc;
+		sc.vertices.resize(vertices.size());
+		sc.triangles.resize(triangles.size());
+		static_assert(sizeof(rtgi_hip::vertex) == sizeof(vertex) && sizeof(rtgi_hip::triangle) == sizeof(triangle), "same records");
+		memcpy((void *)sc.vertices.data(), vertices.data(), vertices.size() * sizeof(vertex));
+		memcpy((void *)sc.triangles.data(), triangles.data(), triangles.size() * sizeof(triangle));
+		rtgi_hip::hip_bvh_frame_tracer frame_rt(false, false, {0});
+		rtgi_hip::ray_tracer *as_base = &frame_rt;
+		std::istringstream sah("sah 8");
+		as_base->interprete("bvh", sah);
+		as_base->build(&sc);
+		std::vector<rtgi_hip::hip_material> mats(5);
+		for (int m = 0; m < 5; ++m)
+			for (int k = 0; k < 3; ++k) mats[m].albedo[k] = albedo[3 * m + k];
+		frame_rt.set_materials(mats);
+		rtgi_frame f{};
+		f.cam = cam;
+		f.sppx = (uint32_t)sppx, f.algo = RTGI_ALGO_LOCAL, f.jitter = 1, f.seed = 0;
+		for (int k = 0; k < 3; ++k) f.light_pos[k] = light_pos[k], f.light_col[k] = light_col[k];
+		const rtgi_frame_stats st = frame_rt.render(f, fb_class.data());
+		const bool same = memcmp(fb_stages.data(), fb_class.data(), fb_stages.size() * 4) == 0;
+		printf("hip_bvh_frame_tracer: %llu rays in %.2f ms, framebuffer %s the stage-by-stage one\n", (unsigned long long)st.rays, st.ms_total,
+		       same ? "identical to" : "DIFFERS from");
+		if (!same) rc = 1;
+	} catch (const std::exception &e) {
+		fprintf(stderr, "hip_bvh_frame_tracer: %s\n", e.what());
+		rc = 1;
+	}
 	rtgi_hip_destroy(rt);
-	return 0;
+	return rc;
 }

@@ -24,9 +24,11 @@
 #include <vector>
 
 #include "rtgi_hip.h"
+#include "rtgi_hip_frame.h"
 
 #ifdef RTGI_HIP_USE_LIBGI
 #include "libgi/rt.h"
+#include "libgi/material.h"
 #include "libgi/scene.h"
 #include "libgi/wavefront-rt.h"
 namespace rtgi_hip {
@@ -112,6 +114,34 @@ struct batch_ray_tracer : public ray_tracer {  // libgi/wavefront-rt.h:10-16
 	virtual void compute_closest_hit() = 0;
 	virtual void compute_any_hit() = 0;
 };
+namespace cpu {
+struct raydata {  // libgi/wavefront-rt.h:24-50 (there the renderer's `resolution` command re-sizes it through
+	int w, h;     // rc->call_at_resolution_change; here the owner calls resize)
+	ray *rays = nullptr;
+	triangle_intersection *intersections = nullptr;
+	raydata(int w, int h) : w(0), h(0) { resize(w, h); }
+	raydata(const raydata &) = delete;
+	raydata &operator=(const raydata &) = delete;
+	~raydata() {
+		delete[] rays;
+		delete[] intersections;
+	}
+	void resize(int new_w, int new_h) {
+		delete[] rays;
+		delete[] intersections;
+		rays = nullptr, intersections = nullptr;
+		w = new_w, h = new_h;
+		if (w > 0 && h > 0) {
+			rays = new ray[(size_t)w * h];
+			intersections = new triangle_intersection[(size_t)w * h];
+		}
+	}
+};
+struct batch_rt : public batch_ray_tracer {  // libgi/wavefront-rt.h:52-56
+	raydata rd;
+	batch_rt(int w = 0, int h = 0) : rd(w, h) {}
+};
+}  // namespace cpu
 }  // namespace wf
 
 }  // namespace rtgi_hip
@@ -170,12 +200,14 @@ public:
 	}
 
 	void closest_hit(const ray *rays, size_t n, triangle_intersection *out) {
+		if (n > 0xffffffffull) throw std::length_error("rtgi_hip: more than 2^32 - 1 rays in one batch");
 		pack(rays, n);
 		check(rtgi_hip_closest_hit(h, staged.data(), (uint32_t)n, reinterpret_cast<rtgi_hit *>(out)));
 	}
 	// compute_any_hit stores the bool through triangle_intersection(uint): t = FLT_MAX, ref = 0 or 1
 	// (libgi/wavefront-rt.h:79, libgi/rt.h:46)
 	void any_hit(const ray *rays, size_t n, triangle_intersection *out) {
+		if (n > 0xffffffffull) throw std::length_error("rtgi_hip: more than 2^32 - 1 rays in one batch");
 		pack(rays, n);
 		occluded.resize(n);
 		check(rtgi_hip_any_hit(h, staged.data(), (uint32_t)n, occluded.data()));
@@ -237,19 +269,16 @@ private:
 	pinned_buffer<uint8_t> occluded;
 };
 
-// The batch interface is the one the GPU is built for: one launch per compute_*() call over n_rays rays.
-// The renderer sizes its ray buffers to the resolution (libgi/wavefront-rt.h:24-50); set_batch() tells the
-// tracer which buffers and how many rays the next compute_*() calls cover.
-class hip_bvh_batch_tracer : public wf::batch_ray_tracer {
+// The batch interface is the one the GPU is built for: one launch per compute_*() call. Like the renderer's
+// batch_rt_adapter (libgi/wavefront-rt.h:58-88) it derives from wf::cpu::batch_rt, whose ray and intersection
+// buffers follow the resolution by themselves (rc->call_at_resolution_change, libgi/wavefront-rt.h:36-43), and
+// traces rd.w * rd.h rays from rd.rays into rd.intersections: an unmodified wavefront algorithm works as it is.
+// A caller with buffers of its own points the base class's `rays` / `intersections` at them with set_batch().
+// compute_*() without any rays to trace throws instead of silently doing nothing.
+class hip_bvh_batch_tracer : public wf::cpu::batch_rt {
 public:
 	hip_bvh_batch_tracer(bool indexed = false, bool esc = false, int device = 0) : core(indexed, esc, device) {}
-	// The intersection buffer is page-locked while it is the current one (it lives until the next `resolution`
-	// command, libgi/wavefront-rt.h:36-43), so that hits arrive in it without a staging copy.
 	void set_batch(ray *r, triangle_intersection *is, size_t n) {
-		if (is != intersections || n != n_rays) {
-			unlock_results();
-			locked_results = is && n && rtgi_hip_host_register(is, n * sizeof(triangle_intersection)) == RTGI_OK;
-		}
 		rays = r;
 		intersections = is;
 		n_rays = n;
@@ -260,17 +289,42 @@ public:
 		core.build(s);
 	}
 	bool interprete(const std::string &command, std::istringstream &in) override { return core.interprete(command, in); }
-	void compute_closest_hit() override { core.closest_hit(rays, n_rays, intersections); }
-	void compute_any_hit() override { core.any_hit(rays, n_rays, intersections); }
+	void compute_closest_hit() override {
+		batch b = current();
+		core.closest_hit(b.rays, b.n, b.out);
+	}
+	void compute_any_hit() override {
+		batch b = current();
+		core.any_hit(b.rays, b.n, b.out);
+	}
 	hip_bvh_core core;
 
 private:
+	struct batch {
+		ray *rays;
+		triangle_intersection *out;
+		size_t n;
+	};
+	// the caller's buffers if set_batch named some, else the renderer-sized ones of the base class
+	batch current() {
+		batch b = rays ? batch{rays, intersections, n_rays} : batch{rd.rays, rd.intersections, rd.w > 0 && rd.h > 0 ? (size_t)rd.w * (size_t)rd.h : 0};
+		if (!b.rays || !b.out || b.n == 0)
+			throw std::logic_error("hip_bvh_batch_tracer: no ray batch to trace (resolution 0x0 and no set_batch)");
+		// The intersection buffer is page-locked while it is the current one, so that hits arrive in it without a
+		// staging copy.
+		if (b.out != locked_ptr || b.n != locked_n) {
+			unlock_results();
+			if (rtgi_hip_host_register(b.out, b.n * sizeof(triangle_intersection)) == RTGI_OK) locked_ptr = b.out, locked_n = b.n;
+		}
+		return b;
+	}
 	void unlock_results() {
-		if (locked_results) rtgi_hip_host_unregister(intersections);
-		locked_results = false;
+		if (locked_ptr) rtgi_hip_host_unregister(locked_ptr);
+		locked_ptr = nullptr, locked_n = 0;
 	}
 	size_t n_rays = 0;
-	bool locked_results = false;
+	triangle_intersection *locked_ptr = nullptr;
+	size_t locked_n = 0;
 };
 
 // Per-ray interface for the renderer's recursive algorithms (gi/primary-hit.cpp:21,36,50). The renderer calls
@@ -288,12 +342,12 @@ public:
 	}
 	bool interprete(const std::string &command, std::istringstream &in) override { return core.interprete(command, in); }
 	triangle_intersection closest_hit(const ray &r) override {
-		request q{&r, false, {}, false};
+		request q{&r, false, {}, false, nullptr};
 		submit(q);
 		return q.result;
 	}
 	bool any_hit(const ray &r) override {
-		request q{&r, true, {}, false};
+		request q{&r, true, {}, false, nullptr};
 		submit(q);
 		return q.result.ref != 0;
 	}
@@ -305,6 +359,7 @@ private:
 		bool any;
 		triangle_intersection result;
 		bool done;
+		std::exception_ptr failure;  // the batch this request travelled in failed: every caller in it gets the exception
 	};
 	std::mutex guard;
 	std::condition_variable served;
@@ -332,11 +387,11 @@ private:
 				failure = std::current_exception();
 			}
 			lock.lock();
-			for (request *p : batch) p->done = true;
+			for (request *p : batch) p->done = true, p->failure = failure;
 			batch_under_way = false;
 			served.notify_all();
-			if (failure) std::rethrow_exception(failure);
 		}
+		if (q.failure) std::rethrow_exception(q.failure);
 	}
 	void serve(const std::vector<request *> &batch) {
 		std::vector<ray> rays;
@@ -356,6 +411,109 @@ private:
 				if (p->any == (any != 0)) p->result = out[k++];
 		}
 	}
+};
+
+// The tracer for whole frames: `raytracer hip [indexed] [esc] [devices N]` as one object that holds a handle per
+// GPU (include/rtgi_hip_frame.h) and, besides the BVH, the part of the scene the shading stages read. It has no
+// per-ray or per-batch entry: the wavefront algorithms of rtgi_hip_algorithms.hpp hand it a whole frame
+// (camera, light, sppx), and rays, hits and the framebuffer stay on the GPUs until the frame is done.
+struct hip_material {  // struct material, libgi/material.h:54-61, as far as the GPU stages read it
+	float albedo[3];
+	float ior = 1.3f, roughness = 0.1f;
+	uint32_t brdf = RTGI_BRDF_LAMBERT;
+};
+class hip_bvh_frame_tracer : public ray_tracer {
+public:
+	hip_bvh_frame_tracer(bool indexed = false, bool esc = false, std::vector<int> devices = {0}) : indexed(indexed) {
+		r = rtgi_hip_renderer_create(devices.data(), (int)devices.size(), indexed ? RTGI_LAYOUT_INDEXED : RTGI_LAYOUT_FLAT, esc ? 1 : 0);
+		if (!r) throw std::runtime_error(std::string("rtgi_hip_renderer_create: ") + rtgi_hip_renderer_last_error(nullptr));
+	}
+	~hip_bvh_frame_tracer() { rtgi_hip_renderer_destroy(r); }
+	hip_bvh_frame_tracer(const hip_bvh_frame_tracer &) = delete;
+	hip_bvh_frame_tracer &operator=(const hip_bvh_frame_tracer &) = delete;
+
+	// ray_tracer::build. Materials are read by materials_of(scene) (inside the renderer: scene->materials; the
+	// stand-alone mirror scene has none, so set_materials() is called by hand); lambertian grey until then.
+	void build(rtgi_hip::scene *s) override {
+		this->scene = s;
+		std::vector<hip_material> m = materials_of(s);
+		std::vector<float> albedo;
+		for (const hip_material &x : m) albedo.insert(albedo.end(), x.albedo, x.albedo + 3);
+		uint32_t top = 0;
+		for (const auto &t : s->triangles) top = t.material_id > top ? t.material_id : top;
+		while (albedo.size() < 3 * ((size_t)top + 1)) albedo.push_back(0.5f);
+		check(rtgi_hip_renderer_build(r, &s->vertices[0].pos, sizeof(s->vertices[0]), (uint32_t)s->vertices.size(), &s->triangles[0].a,
+		                              sizeof(s->triangles[0]), (uint32_t)s->triangles.size(), albedo.data(), (uint32_t)(albedo.size() / 3)));
+		n_materials = (uint32_t)(albedo.size() / 3);
+		if (!m.empty()) set_materials(m);
+		if (!indexed) {  // commit_shuffled_triangles, rt/bbvh-base/bvh2.cpp:172-180
+			rtgi_hip_tracer *h = rtgi_hip_renderer_handle(r, 0);
+			std::vector<uint32_t> order(rtgi_hip_num_index(h));
+			if (rtgi_hip_get_triangle_order(h, order.data()) < 0) throw std::runtime_error(rtgi_hip_last_error(h));
+			auto shuffled = s->triangles;
+			for (size_t i = 0; i < order.size(); ++i) shuffled[i] = s->triangles[order[i]];
+			s->triangles = std::move(shuffled);
+		}
+	}
+	// `material ...` commands after `commit` (driver/interaction.cpp:250-327): the table may be replaced at any time
+	void set_materials(const std::vector<hip_material> &m) {
+		if (m.size() != n_materials) throw std::invalid_argument("hip_bvh_frame_tracer: as many materials as the committed scene has");
+		std::vector<rtgi_material> c(m.size());
+		for (size_t i = 0; i < m.size(); ++i) c[i] = rtgi_material{{m[i].albedo[0], m[i].albedo[1], m[i].albedo[2]}, m[i].ior, m[i].roughness, m[i].brdf};
+		check(rtgi_hip_renderer_set_materials(r, c.data(), (uint32_t)c.size()));
+	}
+	// the scene's material table as it is now (inside the renderer; a no-op for the stand-alone mirror scene)
+	void refresh_materials() {
+		std::vector<hip_material> m = materials_of(this->scene);
+		if (!m.empty()) set_materials(m);
+	}
+	bool interprete(const std::string &command, std::istringstream &in) override {
+		std::string rest;
+		std::getline(in, rest);
+		int rc = rtgi_hip_renderer_interprete(r, command.c_str(), rest.c_str());
+		if (rc < 0) {
+			fprintf(stderr, "command  (%s): %s\n", command.c_str(), rtgi_hip_renderer_last_error(r));
+			return true;
+		}
+		return rc == 1;
+	}
+	// One frame: framebuffer.clear, sppx samples per pixel, framebuffer::add per sample (run(algo) of
+	// driver/main.cpp:38-48 with a wavefront algorithm). framebuffer: w*h x (mean rgb, sample count), the layout of
+	// rc->framebuffer.color (libgi/framebuffer.h:13-50: vec4 per pixel, row y at y*w).
+	rtgi_frame_stats render(const rtgi_frame &f, float *framebuffer) {
+		rtgi_frame_stats st;
+		check(rtgi_hip_renderer_render(r, &f, framebuffer, nullptr, &st));
+		return st;
+	}
+	rtgi_hip_renderer *renderer() { return r; }
+
+private:
+	void check(int rc) {
+		if (rc < 0) throw std::runtime_error(std::string("rtgi_hip: ") + rtgi_hip_renderer_last_error(r));
+	}
+#ifdef RTGI_HIP_USE_LIBGI
+	// brdf objects carry no name: the kind is told by the dynamic type (libgi/material.h:21-51)
+	static uint32_t brdf_kind(::brdf *f) {
+		if (auto *l = dynamic_cast<layered_brdf *>(f)) return dynamic_cast<gtr2_reflection *>(l->coat) ? RTGI_BRDF_LAYERED_GTR2 : RTGI_BRDF_LAYERED_PHONG;
+		if (dynamic_cast<phong_specular_reflection *>(f)) return RTGI_BRDF_PHONG;
+		if (dynamic_cast<gtr2_reflection *>(f)) return RTGI_BRDF_GTR2;
+		return RTGI_BRDF_LAMBERT;
+	}
+	static std::vector<hip_material> materials_of(rtgi_hip::scene *s) {
+		std::vector<hip_material> m(s->materials.size());
+		for (size_t i = 0; i < m.size(); ++i) {
+			const ::material &x = s->materials[i];
+			m[i].albedo[0] = x.albedo.x, m[i].albedo[1] = x.albedo.y, m[i].albedo[2] = x.albedo.z;
+			m[i].ior = x.ior, m[i].roughness = x.roughness, m[i].brdf = brdf_kind(x.brdf);
+		}
+		return m;
+	}
+#else
+	static std::vector<hip_material> materials_of(rtgi_hip::scene *) { return {}; }
+#endif
+	rtgi_hip_renderer *r = nullptr;
+	bool indexed;
+	uint32_t n_materials = 0;
 };
 
 }  // namespace rtgi_hip

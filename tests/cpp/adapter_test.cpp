@@ -210,6 +210,67 @@ int main(int argc, char **argv) {
 			printf("batch interface on host buffers: %.0f Mrays/s (2^20 rays per call, packing and copies included)\n", big / dt / 1e6);
 			hb->set_batch(rays.data(), got.data(), rays.size());
 		}
+		// an unmodified wavefront algorithm fills the tracer's own resolution-sized buffers (wf::cpu::batch_rt::rd,
+		// libgi/wavefront-rt.h:52-56) and calls compute_*() without further ado
+		{
+			rtgi_hip::scene sc5;
+			make_soup(sc5, n_tris, 7);
+			hip_bvh_batch_tracer own(/*indexed*/ true);
+			own.build(&sc5);
+			bool threw = false;
+			try {
+				own.compute_closest_hit();  // resolution 0x0: nothing to trace is an error, not a silent no-op
+			} catch (const std::logic_error &) {
+				threw = true;
+			}
+			EXPECT(threw);
+			own.rd.resize(100, 64);  // `resolution 100 64`
+			for (int i = 0; i < 6400; ++i) own.rd.rays[i] = rays[i];
+			wf::batch_ray_tracer *as_batch = &own;
+			as_batch->compute_closest_hit();
+			std::vector<triangle_intersection> w5(6400);
+			void *o5 = orc_bbvh_build(pos.data(), (uint32_t)sc5.vertices.size(), tri.data(), (uint32_t)sc5.triangles.size(), 1, 0, 0, 0, 1);
+			orc_bbvh_closest_hit(o5, rays8.data(), 6400, w5.data(), nullptr, nullptr, 0);
+			orc_bbvh_destroy(o5);
+			bool same_own = true;
+			for (int i = 0; i < 6400; ++i) same_own = same_own && memcmp(&own.rd.intersections[i].t, &w5[i].t, 4) == 0 && own.rd.intersections[i].ref == w5[i].ref;
+			EXPECT(same_own);
+		}
+		// the frame tracer (`raytracer hip devices ...`): one GPU named twice renders the frame of one handle
+		{
+			rtgi_hip::scene s6, s7;
+			make_soup(s6, n_tris, 7);
+			make_soup(s7, n_tris, 7);
+			for (size_t i = 0; i < s6.triangles.size(); ++i) s6.triangles[i].material_id = s7.triangles[i].material_id = (uint32_t)(i % 3);
+			hip_bvh_frame_tracer one(false, false, {0}), two(false, false, {0, 0});
+			one.build(&s6);
+			two.build(&s7);
+				std::vector<hip_material> mats(3);
+			for (int m = 0; m < 3; ++m) mats[m].albedo[0] = 0.2f + 0.3f * m, mats[m].albedo[1] = 0.5f, mats[m].albedo[2] = 0.9f - 0.3f * m, mats[m].brdf = (uint32_t)m;
+			mats[1].roughness = 0.3f;
+			one.set_materials(mats);
+			two.set_materials(mats);
+			rtgi_frame f{};
+			f.cam = rtgi_camera{{0, 0, -1}, {0, 0, 14}, {0, 1, 0}, 65.0f, 160, 100};
+			f.sppx = 3, f.algo = RTGI_ALGO_LOCAL, f.jitter = 1, f.seed = 5, f.sharding = RTGI_SHARD_TILES, f.tile = 16;
+			f.light_pos[0] = 0, f.light_pos[1] = 12, f.light_pos[2] = 12;
+			f.light_col[0] = f.light_col[1] = f.light_col[2] = 30.0f;
+			std::vector<float> fb1(160 * 100 * 4), fb2(fb1.size());
+			const rtgi_frame_stats st1 = one.render(f, fb1.data()), st2 = two.render(f, fb2.data());
+			EXPECT(st1.rays == st2.rays && st2.n_devices == 2);
+			EXPECT(memcmp(fb1.data(), fb2.data(), fb1.size() * 4) == 0);
+			double sum = 0;
+			bool counts = true;
+			for (size_t i = 0; i < fb1.size(); i += 4) sum += fb1[i] + fb1[i + 1] + fb1[i + 2], counts = counts && fb1[i + 3] == 3.0f;
+			EXPECT(counts && sum > 0);
+			bool refused = false;
+			try {
+				one.set_materials(std::vector<hip_material>(2));
+			} catch (const std::invalid_argument &) {
+				refused = true;
+			}
+			EXPECT(refused);
+		}
 		printf("gpu: %d rays, %d hits\n", n_rays, hits);
 	}
 	orc_bbvh_destroy(o);
