@@ -483,3 +483,21 @@ def test_degenerate_triangles_and_pathological_rays():
     want, want_counts = o.closest_hit(big, counts=True)
     want_any, want_any_counts = o.any_hit(big, counts=True)
     _check_device_path(t, big, want, want_counts, want_any, want_any_counts)
+
+
+def test_handle_on_another_gpu_than_the_current_one():
+    """Build, probe and trace on GPU 1 while GPU 0 is the caller's current device (what `raytracer hip device 1` does
+    in a host program that never selects a device): every buffer of the handle must live on its own GPU."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    torch.cuda.set_device(0)
+    pos, tri, _ = scenes.soup(6000, seed=4)  # more than 4096 leaf slots: the probe rays of "hip reorder auto" run
+    t = tracer.HipBvhTracer(layout="indexed", device=1)
+    t.build(pos, tri)
+    assert torch.cuda.current_device() == 0 and t.incoherent_ray_cost > 0
+    rays = rays_toward_scene(pos, 40000, 3)
+    o = orc.Bbvh(pos, tri, layout="indexed")
+    assert_hits_equal(t.closest_hit(rays), o.closest_hit(rays), "host batch on GPU 1")
+    assert np.array_equal(t.any_hit(rays), o.any_hit(rays))
+    assert torch.cuda.current_device() == 0
