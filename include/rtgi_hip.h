@@ -154,7 +154,7 @@ int rtgi_hip_any_hit_device(rtgi_hip_tracer *h, const rtgi_ray *d_rays, uint32_t
  * memory (ray counters, the four arrays and the scratch of the ray sort, the stack spill area of deep trees) is a
  * fixed 44 MiB array inside the library's code object, one copy per GPU, held until the process ends. At most
  * 2^21 = 2097152 rays per call, more is refused with RTGI_ERR_INVALID. Where something does not fit, the call adapts
- * instead of failing: a sort whose scratch would not fit is left out, and for trees deeper than the 24 stack levels
+ * instead of failing: a sort whose scratch would not fit is left out, and for trees deeper than the 24 stack levels that can be
  * kept in LDS the launch uses as many workgroups as the 8 MiB spill area gives stacks to. All calls on one GPU,
  * from any handle, share that GPU's array: calls that overlap in time on one GPU race; order them on one stream
  * or with events. */

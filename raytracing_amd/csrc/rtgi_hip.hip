@@ -24,7 +24,6 @@
 #include "wavefront_kernels.h"
 
 using rtgi_dev::BLOCK;
-using rtgi_dev::STACK_LDS;
 using rtgi_dev::TraceArgs;
 using rtgi_dev::trace_kernel;
 
@@ -192,9 +191,12 @@ struct rtgi_hip_tracer {
 	float reorder_min_pops = 120.0f;
 	std::vector<rtgi_ray> probe_rays;
 	uint32_t node_bytes = 0, tri_bytes = 0;
-	int refill_min = 16, leaf_min = 8, drain_leaf_min = 4;
+	int refill_min = 24, leaf_min = 12, drain_leaf_min = 4;
 	bool top_in_lds = true;
-	uint32_t blocks_per_cu = 3;
+	uint32_t blocks_per_cu = 1;
+	// division of a workgroup's LDS (set at upload from the tree's depth and size, see trace_kernel.h)
+	uint32_t stack_levels = 1, top_nodes = 0, lds_bytes = 0;
+	int force_stack_levels = 0, max_top_nodes = 1 << 30;
 	uint32_t n_segments = 8;
 	int32_t *d_spill = nullptr;
 	uint32_t *d_counter = nullptr;
@@ -274,6 +276,8 @@ void read_tunables(rtgi_hip_tracer *h) {
 	h->drain_leaf_min = number("RTGI_HIP_DRAIN_LEAF_MIN", 1, 64, h->drain_leaf_min);
 	h->n_segments = number("RTGI_HIP_SEGMENTS", 1, 8, 8) == 1 ? 1u : 8u;
 	h->top_in_lds = number("RTGI_HIP_TOP_IN_LDS", 0, 1, 1) != 0;
+	h->force_stack_levels = number("RTGI_HIP_STACK_LEVELS", 0, 64, 0);
+	h->max_top_nodes = number("RTGI_HIP_TOP_NODES", 0, 1 << 30, h->max_top_nodes);
 	h->reorder = number("RTGI_HIP_REORDER", 0, 2, h->reorder);
 	h->host_chunk = (uint32_t)number("RTGI_HIP_HOST_CHUNK", 1 << 16, 1 << 30, (int)h->host_chunk);
 	h->host_direct = number("RTGI_HIP_HOST_DIRECT", 0, 1, 1) != 0;
@@ -288,12 +292,22 @@ int upload(rtgi_hip_tracer *h, const rtgi::SceneView &scene) {
 	free_device_tree(h);
 	hipDeviceProp_t prop;
 	HIP_TRY(h, hipGetDeviceProperties(&prop, h->device));
-	// persistent grid: workgroups of 4 waves, one wave per SIMD each, 3 per CU (2 are clearly slower, 4 gain nothing
-	// and leave each lane fewer rays to amortise its drain phase over)
+	// persistent grid: one workgroup of 16 waves per CU (four per SIMD), which owns the CU's LDS
 	h->grid_blocks = (uint32_t)prop.multiProcessorCount * h->blocks_per_cu;
-	// a near-first depth-first walk never has more pending entries than one per level
-	// of the tree's depth (the entry in flight sits in a register, its pending siblings in memory)
-	h->spill_levels = flat.depth > (uint32_t)STACK_LDS ? flat.depth - STACK_LDS : 0;
+	// A near-first depth-first walk never has more pending entries than one per level of the tree's depth (the
+	// entry in flight sits in a register, its pending siblings in memory): the LDS holds that many slots per lane,
+	// and the first nodes of the breadth-first numbering in what is left. Deeper trees keep DEEP_STACK_LDS slots
+	// in LDS and the rest of the stack in a global spill area.
+	const uint32_t lds_cu = prop.maxSharedMemoryPerMultiProcessor >= 65536 ? (uint32_t)prop.maxSharedMemoryPerMultiProcessor : 65536u;
+	const uint32_t lds_budget = std::min<uint32_t>(lds_cu / h->blocks_per_cu, 160u << 10);
+	h->stack_levels = flat.depth <= (uint32_t)rtgi_dev::MAX_STACK_LDS ? std::max<uint32_t>(flat.depth, 1) : (uint32_t)rtgi_dev::DEEP_STACK_LDS;
+	if (h->force_stack_levels) h->stack_levels = (uint32_t)h->force_stack_levels;
+	while (h->stack_levels > 1 && (size_t)h->stack_levels * BLOCK * sizeof(int32_t) > lds_budget) --h->stack_levels;
+	h->spill_levels = flat.depth > h->stack_levels ? flat.depth - h->stack_levels : 0;
+	const size_t stack_bytes = (size_t)h->stack_levels * BLOCK * sizeof(int32_t);
+	if (stack_bytes > lds_budget) return fail(h, RTGI_ERR_DEVICE, "this GPU's LDS does not hold one stack slot per lane");
+	h->top_nodes = h->top_in_lds ? (uint32_t)std::min<size_t>({(lds_budget - stack_bytes) / 64, (size_t)flat.n_inner, (size_t)h->max_top_nodes}) : 0;
+	h->lds_bytes = (uint32_t)(stack_bytes + (size_t)h->top_nodes * 64);
 	// buffer descriptors address the arrays with 32-bit byte offsets
 	if (flat.n_inner >= (1u << 25) || flat.n_slots >= 44000000u)
 		return fail(h, RTGI_ERR_INVALID, "scene too large: at most 2^25 inner nodes and 44M leaf slots");
@@ -464,16 +478,30 @@ int sort_rays(rtgi_hip_tracer *h, const BatchView *batches, uint32_t n_batches, 
 	return RTGI_OK;
 }
 
+// A launch with `lds` bytes of dynamic LDS. More than 64 KiB needs the kernel's limit raised first: once per kernel
+// instantiation and GPU.
+template <int MODE, bool COUNT, bool DEEP>
+hipError_t launch_kernel(int device, uint32_t blocks, uint32_t lds, hipStream_t stream, const TraceArgs &a) {
+	static std::mutex guard;
+	static bool raised[64] = {};
+	if (device >= 0 && device < 64) {
+		std::lock_guard<std::mutex> lock(guard);
+		if (!raised[device]) {
+			hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&trace_kernel<MODE, COUNT, DEEP>),
+			                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
+			if (e != hipSuccess) return e;
+			raised[device] = true;
+		}
+	}
+	hipLaunchKernelGGL((trace_kernel<MODE, COUNT, DEEP>), dim3(blocks), dim3(BLOCK), lds, stream, a);
+	return hipGetLastError();
+}
 template <int MODE>
-void launch_variant(bool count, bool deep, uint32_t blocks, hipStream_t stream, const TraceArgs &a) {
-	if (count && deep)
-		hipLaunchKernelGGL((trace_kernel<MODE, true, true>), dim3(blocks), dim3(BLOCK), 0, stream, a);
-	else if (count)
-		hipLaunchKernelGGL((trace_kernel<MODE, true, false>), dim3(blocks), dim3(BLOCK), 0, stream, a);
-	else if (deep)
-		hipLaunchKernelGGL((trace_kernel<MODE, false, true>), dim3(blocks), dim3(BLOCK), 0, stream, a);
-	else
-		hipLaunchKernelGGL((trace_kernel<MODE, false, false>), dim3(blocks), dim3(BLOCK), 0, stream, a);
+hipError_t launch_variant(int device, bool count, bool deep, uint32_t blocks, uint32_t lds, hipStream_t stream, const TraceArgs &a) {
+	if (count && deep) return launch_kernel<MODE, true, true>(device, blocks, lds, stream, a);
+	if (count) return launch_kernel<MODE, true, false>(device, blocks, lds, stream, a);
+	if (deep) return launch_kernel<MODE, false, true>(device, blocks, lds, stream, a);
+	return launch_kernel<MODE, false, false>(device, blocks, lds, stream, a);
 }
 
 // Records the "scratch is free again" event when a launch sequence ends, on every path out of it.
@@ -595,8 +623,10 @@ int launch_batches(rtgi_hip_tracer *h, const BatchView *given, uint32_t n_given,
 	a.refill_min = h->refill_min;
 	a.leaf_min = h->leaf_min;
 	a.drain_leaf_min = h->drain_leaf_min;
-	a.top_nodes = h->top_in_lds ? rtgi_dev::TOP_NODES : 0;
-	uint32_t blocks = (n + BLOCK - 1) / BLOCK;
+	a.top_nodes = (int32_t)h->top_nodes;
+	a.stack_levels = (int32_t)h->stack_levels;
+	// (a small batch still spreads over the CUs: a workgroup per 256 rays, its other waves find the supply dry at once)
+	uint32_t blocks = (n + 255) / 256;
 	if (blocks > h->grid_blocks) blocks = h->grid_blocks;
 	const bool deep = h->spill_levels > 0;  // the tree is deeper than the LDS part of the stack
 	if (deep) {  // every lane of the grid owns spill_levels words of the spill area
@@ -627,12 +657,14 @@ int launch_batches(rtgi_hip_tracer *h, const BatchView *given, uint32_t n_given,
 		++h->events_used;
 		HIP_TRY(h, hipEventRecord(ev_start, stream));
 	}
+	hipError_t launched;
 	if (mode == 2)
-		launch_variant<2>(false, deep, blocks, stream, a);
+		launched = launch_variant<2>(h->device, false, deep, blocks, h->lds_bytes, stream, a);
 	else if (mode == 1)
-		launch_variant<1>(d_counts != nullptr, deep, blocks, stream, a);
+		launched = launch_variant<1>(h->device, d_counts != nullptr, deep, blocks, h->lds_bytes, stream, a);
 	else
-		launch_variant<0>(d_counts != nullptr, deep, blocks, stream, a);
+		launched = launch_variant<0>(h->device, d_counts != nullptr, deep, blocks, h->lds_bytes, stream, a);
+	HIP_TRY(h, launched);
 	if (ev_stop) HIP_TRY(h, hipEventRecord(ev_stop, stream));
 	if (!fixed)
 		if (int rc = turn.end()) return rc;

@@ -5,7 +5,7 @@
 // closest_hit, its entry distance is below the closest t so far; triangles by Cramer's rule in the operation
 // order of libgi/intersect.h:43-57; slab test of libgi/intersect.h:204-236.
 //
-// One ray per lane, wave64, persistent workgroups. While rays are in supply the kernel is bound by the rate of
+// One ray per lane, wave64, one persistent workgroup per CU. While rays are in supply the kernel is bound by the rate of
 // random 64-byte node fetches below L1, at the end of a launch by the latency of its longest rays; the
 // structure keeps lanes busy and instructions per useful lane-step few:
 //  * a wave refills finished lanes from a global ray counter instead of waiting for its slowest ray;
@@ -16,10 +16,10 @@
 //  * loads go through buffer descriptors: a 32-bit per-lane offset instead of 64-bit address arithmetic,
 //    and an out-of-range index reads zeros instead of faulting;
 //  * the pending-node stack keeps its top in a register and the rest in LDS as [level][lane] (any mix of
-//    depths is conflict-free); trees deeper than STACK_LDS use the DEEP variant, which continues the stack
+//    depths is conflict-free); trees deeper than MAX_STACK_LDS use the DEEP variant, which continues the stack
 //    in a global area sized from the tree depth, so the stack cannot overflow;
-//  * the first TOP_NODES nodes of the breadth-first numbering, which every ray visits, are read from a copy in
-//    LDS;
+//  * the first nodes of the breadth-first numbering, which every ray visits, are read from a copy in LDS (as
+//    many as fit beside the stacks);
 //  * large batches are traced through a permutation (octant, length class, Morton code of the origin), each XCD
 //    starting on the rays of one direction octant, the long rays first.
 #pragma once
@@ -32,21 +32,23 @@
 
 namespace rtgi_dev {
 
-constexpr int BLOCK = 256;      // 4 waves per workgroup
-#ifndef RTGI_STACK_LDS
-#define RTGI_STACK_LDS 24
+// One workgroup of 16 waves per CU (four per SIMD), so that the CU's 160 KiB of LDS hold ONE copy of the top of the
+// tree beside the stacks: the launch divides the LDS between `stack_levels` pending-node slots per lane and as many
+// of the first nodes of the breadth-first numbering as fit in the rest (2^20 triangles, depth 20: 80 KiB of stacks,
+// 1280 nodes = the upper ten levels; a small scene's whole tree).
+#ifndef RTGI_BLOCK
+#define RTGI_BLOCK 1024
 #endif
-constexpr int STACK_LDS = RTGI_STACK_LDS;  // pending nodes per lane held in LDS (beyond the one in a register)
+constexpr int BLOCK = RTGI_BLOCK;  // threads per workgroup
+constexpr int MAX_STACK_LDS = 24;  // at most this many pending nodes per lane in LDS (beyond the one in a register)
+constexpr int DEEP_STACK_LDS = 20; // trees deeper than MAX_STACK_LDS: this many in LDS, the rest in the global spill area
 constexpr int COUNTER_STRIDE = 32;
-#ifndef RTGI_TOP_NODES
-#define RTGI_TOP_NODES 256
-#endif
-constexpr int TOP_NODES = RTGI_TOP_NODES;  // inner nodes 0..TOP_NODES-1 (the top of the breadth-first numbering) are kept in LDS
 constexpr int MAX_BATCHES = 8;
 constexpr int32_t IDLE = INT32_MIN;  // lane has no ray; leaf references are ~slot with slot < 2^30
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 struct TraceArgs {
 	const void *nodes;      // 64 B per inner node, see flatten_tree() in bvh_host.cpp
@@ -58,7 +60,7 @@ struct TraceArgs {
 	uint8_t *occluded;      // any_hit output
 	uint32_t *counts;       // optional: 2 per ray
 	unsigned long long *totals;  // optional, counting kernels only: sums over the launch, see finish()
-	int32_t *spill;         // DEEP only: [level - STACK_LDS][global lane]
+	int32_t *spill;         // DEEP only: [level - stack_levels][global lane]
 	uint32_t *ray_counter;  // n_segments counters, COUNTER_STRIDE words apart (one cache line each)
 	uint32_t n_rays;
 	uint32_t n_segments;    // the ray range is cut into this many contiguous segments (1 or 8)
@@ -75,7 +77,8 @@ struct TraceArgs {
 	const float4 *batch_rays[MAX_BATCHES];
 	void *batch_out[MAX_BATCHES];       // float4 per ray (closest_hit) or one byte per ray (any_hit)
 	uint32_t batch_any;                 // bit b: batch b is an any_hit batch
-	int32_t top_nodes;      // 0, or TOP_NODES: visits to the first nodes are served from a copy in LDS
+	int32_t top_nodes;      // visits to inner nodes 0 .. top_nodes-1 are served from a copy in LDS
+	int32_t stack_levels;   // pending-node slots per lane in LDS; dynamic LDS = stack_levels * BLOCK * 4 + top_nodes * 64 bytes
 #ifdef RTGI_DIAG
 	unsigned long long *diag;  // diagnostic build only: 8 counters summed over all waves
 #endif
@@ -116,8 +119,10 @@ __device__ __forceinline__ float next_up(float x) {
 template <int MODE, bool COUNT, bool DEEP>
 __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 	constexpr bool MIXED = MODE == 2;
-	__shared__ int32_t s_stack[STACK_LDS][BLOCK];
-	__shared__ u32x4 s_top[4][TOP_NODES];  // [quad][node]: lanes on different nodes read different 16-byte slots
+	extern __shared__ __align__(16) unsigned char s_mem[];
+	const int32_t stack_levels = a.stack_levels;
+	int32_t *const s_stack = reinterpret_cast<int32_t *>(s_mem);  // [level][thread]: bank = lane, conflict-free for any mix of depths
+	u32x4 *const s_top = reinterpret_cast<u32x4 *>(s_mem + (size_t)stack_levels * BLOCK * sizeof(int32_t));  // [quad][node]: lanes on different nodes read different 16-byte slots
 	const int tid = threadIdx.x;
 	const int lane = tid & 63;
 	const uint32_t gl = blockIdx.x * BLOCK + tid;
@@ -130,8 +135,8 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 	// rate is what the kernel runs against. (Reads beyond the node array return zeros.)
 	const int32_t top_nodes = a.top_nodes;
 	if (top_nodes) {
-		for (int i = tid; i < 4 * TOP_NODES; i += BLOCK)
-			s_top[i & 3][i >> 2] = __builtin_amdgcn_raw_buffer_load_b128(node_rsrc, i << 4, 0, 0);
+		for (int i = tid; i < 4 * top_nodes; i += BLOCK)
+			s_top[(i & 3) * top_nodes + (i >> 2)] = __builtin_amdgcn_raw_buffer_load_b128(node_rsrc, i << 4, 0, 0);
 		__syncthreads();
 	}
 
@@ -157,16 +162,16 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 	uint32_t segs_done = 0;
 
 	auto push = [&](int32_t v) {
-		if (!DEEP || sp < STACK_LDS)
-			s_stack[sp][tid] = v;
+		if (!DEEP || sp < stack_levels)
+			s_stack[sp * BLOCK + tid] = v;
 		else
-			a.spill[(size_t)(sp - STACK_LDS) * a.spill_stride + gl] = v;
+			a.spill[(size_t)(sp - stack_levels) * a.spill_stride + gl] = v;
 		++sp;
 	};
 	auto pop = [&]() -> int32_t {
 		--sp;
-		if (!DEEP || sp < STACK_LDS) return s_stack[sp][tid];
-		return a.spill[(size_t)(sp - STACK_LDS) * a.spill_stride + gl];
+		if (!DEEP || sp < stack_levels) return s_stack[sp * BLOCK + tid];
+		return a.spill[(size_t)(sp - stack_levels) * a.spill_stride + gl];
 	};
 	auto finish = [&]() {
 		if (MIXED) {
@@ -276,6 +281,55 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 		// once leaf_min lanes have left it (reached a leaf or finished their ray), or nobody is left --------
 		auto inner_phase = [&](auto plain_tag) {
 			constexpr bool PLAIN = decltype(plain_tag)::value;
+			// one step of one lane: the two child boxes of its node against its ray, then down, or on to a pending node
+			auto step = [&](const u32x4 q0, const u32x4 q1, const u32x4 q2, const int32_t link_l, const int32_t link_r) {
+				if (COUNT) ++n_inner;
+				auto pair = [](uint32_t u, uint32_t v) { return f32x2{__uint_as_float(u), __uint_as_float(v)}; };
+				// .x = left child, .y = right child; (box - o) * id as in libgi/intersect.h:210-221
+				const f32x2 ax = (pair(q0.x, q0.y) - f32x2{ox, ox}) * f32x2{ix, ix};
+				const f32x2 ay = (pair(q0.z, q0.w) - f32x2{oy, oy}) * f32x2{iy, iy};
+				const f32x2 az = (pair(q1.x, q1.y) - f32x2{oz, oz}) * f32x2{iz, iz};
+				const f32x2 bx = (pair(q1.z, q1.w) - f32x2{ox, ox}) * f32x2{ix, ix};
+				const f32x2 by = (pair(q2.x, q2.y) - f32x2{oy, oy}) * f32x2{iy, iy};
+				const f32x2 bz = (pair(q2.z, q2.w) - f32x2{oz, oz}) * f32x2{iz, iz};
+				float dl, dr;
+				bool hl, hr;
+				if (PLAIN) {
+					// no NaN possible: the selects of intersect.h:212-228 are exact min / max, and
+					// !(t1 > t2) && !(t2 < t_min) && !(t1 > t_max) [&& t1 < closest t] folds into two compares
+					dl = vmax3(vmin(ax.x, bx.x), vmin(ay.x, by.x), vmin(az.x, bz.x));
+					dr = vmax3(vmin(ax.y, bx.y), vmin(ay.y, by.y), vmin(az.y, bz.y));
+					const float fl = vmin3(vmax(ax.x, bx.x), vmax(ay.x, by.x), vmax(az.x, bz.x));
+					const float fr = vmin3(vmax(ax.y, bx.y), vmax(ay.y, by.y), vmax(az.y, bz.y));
+					hl = (vmax(dl, t_min) <= fl) && (dl < lim);
+					hr = (vmax(dr, t_min) <= fr) && (dr < lim);
+				} else {
+					auto slab = [&](float a_x, float b_x, float a_y, float b_y, float a_z, float b_z, float &entry) {
+						float nx = (a_x < b_x) ? a_x : b_x, fx = (b_x < a_x) ? a_x : b_x;
+						float ny = (a_y < b_y) ? a_y : b_y, fy = (b_y < a_y) ? a_y : b_y;
+						float nz = (a_z < b_z) ? a_z : b_z, fz = (b_z < a_z) ? a_z : b_z;
+						float t1 = (nx < ny) ? ny : nx;
+						t1 = (nz < t1) ? t1 : nz;
+						float t2 = (fx < fy) ? fx : fy;
+						t2 = (fz < t2) ? fz : t2;
+						entry = t1;
+						bool hit = !(t1 > t2) && !(t2 < t_min) && !(t1 > t_max);
+						if (!any_lane) hit = hit && t1 < best_t;  // bvh2.cpp:432-433; not in any_hit (:476-477)
+						return hit;
+					};
+					hl = slab(ax.x, bx.x, ay.x, by.x, az.x, bz.x, dl);
+					hr = slab(ax.y, bx.y, ay.y, by.y, az.y, bz.y, dr);
+				}
+				// bvh2.cpp:434-446: both hit -> nearer first, the right child on a tie, the other one pending
+				const bool left_first = hl && ((dl < dr) || !hr);
+				const int32_t first = left_first ? link_l : link_r;
+				const int32_t second = left_first ? link_r : link_l;
+				if (hl && hr) push(second);
+				if (hl || hr)
+					cur = first;
+				else
+					advance();
+			};
 			for (;;) {
 				const bool at_inner = cur >= 0;
 				if ((int)__popcll(__ballot(at_inner)) <= keep_going) break;
@@ -284,64 +338,24 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 				else ++dg_it_drain, dg_ln_drain += __popcll(__ballot(at_inner));
 #endif
 				if (at_inner) {
-					const int voff = cur << 6;
-					u32x4 q0, q1, q2, q3;
+					// (One pass over the step code for all lanes, whether their node comes from LDS or from memory: letting
+					// the lanes inside the LDS part take extra steps while the others' loads are under way was measured and
+					// costs 3 % at one extra pass and 20 % at three -- the passes with few active lanes take vector issue
+					// slots from the other three waves of the SIMD.)
+					u32x4 q0, q1, q2;
+					u32x2 q3;
 					if (cur < top_nodes) {
-						q0 = s_top[0][cur], q1 = s_top[1][cur], q2 = s_top[2][cur], q3 = s_top[3][cur];
+						const u32x4 l3 = s_top[3 * top_nodes + cur];
+						q0 = s_top[cur], q1 = s_top[top_nodes + cur], q2 = s_top[2 * top_nodes + cur], q3 = u32x2{l3.x, l3.y};
 						if (COUNT) ++n_top;
 					} else {
+						const int voff = cur << 6;
 						q0 = __builtin_amdgcn_raw_buffer_load_b128(node_rsrc, voff, 0, 0);
 						q1 = __builtin_amdgcn_raw_buffer_load_b128(node_rsrc, voff + 16, 0, 0);
 						q2 = __builtin_amdgcn_raw_buffer_load_b128(node_rsrc, voff + 32, 0, 0);
-						q3 = __builtin_amdgcn_raw_buffer_load_b128(node_rsrc, voff + 48, 0, 0);
+						q3 = __builtin_amdgcn_raw_buffer_load_b64(node_rsrc, voff + 48, 0, 0);
 					}
-					if (COUNT) ++n_inner;
-					auto pair = [](uint32_t u, uint32_t v) { return f32x2{__uint_as_float(u), __uint_as_float(v)}; };
-					// .x = left child, .y = right child; (box - o) * id as in libgi/intersect.h:210-221
-					const f32x2 ax = (pair(q0.x, q0.y) - f32x2{ox, ox}) * f32x2{ix, ix};
-					const f32x2 ay = (pair(q0.z, q0.w) - f32x2{oy, oy}) * f32x2{iy, iy};
-					const f32x2 az = (pair(q1.x, q1.y) - f32x2{oz, oz}) * f32x2{iz, iz};
-					const f32x2 bx = (pair(q1.z, q1.w) - f32x2{ox, ox}) * f32x2{ix, ix};
-					const f32x2 by = (pair(q2.x, q2.y) - f32x2{oy, oy}) * f32x2{iy, iy};
-					const f32x2 bz = (pair(q2.z, q2.w) - f32x2{oz, oz}) * f32x2{iz, iz};
-					const int32_t link_l = (int32_t)q3.x, link_r = (int32_t)q3.y;
-					float dl, dr;
-					bool hl, hr;
-					if (PLAIN) {
-						// no NaN possible: the selects of intersect.h:212-228 are exact min / max, and
-						// !(t1 > t2) && !(t2 < t_min) && !(t1 > t_max) [&& t1 < closest t] folds into two compares
-						dl = vmax3(vmin(ax.x, bx.x), vmin(ay.x, by.x), vmin(az.x, bz.x));
-						dr = vmax3(vmin(ax.y, bx.y), vmin(ay.y, by.y), vmin(az.y, bz.y));
-						const float fl = vmin3(vmax(ax.x, bx.x), vmax(ay.x, by.x), vmax(az.x, bz.x));
-						const float fr = vmin3(vmax(ax.y, bx.y), vmax(ay.y, by.y), vmax(az.y, bz.y));
-						hl = (vmax(dl, t_min) <= fl) && (dl < lim);
-						hr = (vmax(dr, t_min) <= fr) && (dr < lim);
-					} else {
-						auto slab = [&](float a_x, float b_x, float a_y, float b_y, float a_z, float b_z, float &entry) {
-							float nx = (a_x < b_x) ? a_x : b_x, fx = (b_x < a_x) ? a_x : b_x;
-							float ny = (a_y < b_y) ? a_y : b_y, fy = (b_y < a_y) ? a_y : b_y;
-							float nz = (a_z < b_z) ? a_z : b_z, fz = (b_z < a_z) ? a_z : b_z;
-							float t1 = (nx < ny) ? ny : nx;
-							t1 = (nz < t1) ? t1 : nz;
-							float t2 = (fx < fy) ? fx : fy;
-							t2 = (fz < t2) ? fz : t2;
-							entry = t1;
-							bool hit = !(t1 > t2) && !(t2 < t_min) && !(t1 > t_max);
-							if (!any_lane) hit = hit && t1 < best_t;  // bvh2.cpp:432-433; not in any_hit (:476-477)
-							return hit;
-						};
-						hl = slab(ax.x, bx.x, ay.x, by.x, az.x, bz.x, dl);
-						hr = slab(ax.y, bx.y, ay.y, by.y, az.y, bz.y, dr);
-					}
-					// bvh2.cpp:434-446: both hit -> nearer first, the right child on a tie, the other one pending
-					const bool left_first = hl && ((dl < dr) || !hr);
-					const int32_t first = left_first ? link_l : link_r;
-					const int32_t second = left_first ? link_r : link_l;
-					if (hl && hr) push(second);
-					if (hl || hr)
-						cur = first;
-					else
-						advance();
+					step(q0, q1, q2, (int32_t)q3.x, (int32_t)q3.y);
 				}
 			}
 		};
