@@ -25,8 +25,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, vendor peak
 # What bounds the traversal is not HBM (nodes and triangles of the 2^20-triangle scene are 112 MiB: they live in the
 # 256 MiB Infinity Cache and mostly in the L2s) but the rate at which a CU's vector memory pipeline takes 16-byte
 # loads whose 64 lanes go to 64 different cache lines. scripts/ubench/gather_mix measures that rate with the
-# kernel's own access shape (dependent random 64-byte records, four loads each, 77 % of them L2 hits, three waves
-# per SIMD); bench.py runs it on the box when the binary is there, else it uses the figure measured for
+# kernel's own access shape (dependent random 64-byte records, four loads each, 77 % of them L2 hits, four waves
+# per SIMD like the kernel); bench.py runs it on the box when the binary is there, else it uses the figure measured for
 # profiles/r02_ubench_gather_mix_3waves.txt.
 LANE_LOADS_PER_S_FALLBACK = 4 * 213.2e9
 MISS_RECORDS_PER_S_FALLBACK = 71.6e9
@@ -199,7 +199,7 @@ def gather_ceiling():
     exe = os.path.join(ROOT, "scripts", "ubench", "gather_mix")
     if os.path.exists(exe):
         try:
-            out = subprocess.run([exe, "3", "quick"], capture_output=True, text=True, timeout=60).stdout
+            out = subprocess.run([exe, "4", "quick"], capture_output=True, text=True, timeout=60).stdout
             vals = dict(line.split() for line in out.splitlines() if line.startswith(("LANE_LOADS", "MISS_RECORDS")))
             return float(vals["LANE_LOADS_PER_S"]), float(vals["MISS_RECORDS_PER_S"]), "measured on this GPU by scripts/ubench/gather_mix"
         except (OSError, KeyError, ValueError, subprocess.SubprocessError):
