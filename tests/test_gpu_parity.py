@@ -243,7 +243,7 @@ def test_upload_of_a_foreign_tree():
 
 
 def test_full_size_soup_properties():
-    # BASELINE-size scene (2^20 triangles): oracle on a sample, size-independent properties on the rest
+    # benchmark-size scene (2^20 triangles): oracle on a sample, size-independent properties on the rest
     import torch
     pos, tri, _ = scenes.soup(1 << 20, seed=1)
     t = tracer.HipBvhTracer(layout="indexed")
