@@ -46,7 +46,7 @@ struct Part {
 	float *d_offsets = nullptr, *d_direct = nullptr, *d_albedo = nullptr, *d_throughput[2] = {nullptr, nullptr};
 	float *d_radiance = nullptr, *d_fb = nullptr, *d_full = nullptr;
 	rtgi_ray *d_rays[2] = {nullptr, nullptr}, *d_shadow = nullptr;
-	rtgi_hit *d_hits = nullptr;
+	rtgi_hit *d_hits = nullptr, *d_hits2 = nullptr;
 	uint8_t *d_occluded = nullptr, *d_rgb = nullptr;
 };
 
@@ -87,13 +87,13 @@ int fail(Part &p, int code, const std::string &msg) {
 void free_buffers(Part &p) {
 	if (hipSetDevice(p.device) != hipSuccess) return;
 	void *all[] = {p.d_pixels, p.d_slot[0], p.d_slot[1], p.d_parent, p.d_count, p.d_offsets, p.d_direct, p.d_albedo, p.d_throughput[0],
-	               p.d_throughput[1], p.d_radiance, p.d_fb, p.d_full, p.d_rays[0], p.d_rays[1], p.d_shadow, p.d_hits, p.d_occluded, p.d_rgb};
+	               p.d_throughput[1], p.d_radiance, p.d_fb, p.d_full, p.d_rays[0], p.d_rays[1], p.d_shadow, p.d_hits, p.d_hits2, p.d_occluded, p.d_rgb};
 	for (void *q : all)
 		if (q) (void)hipFree(q);
 	p.d_pixels = p.d_slot[0] = p.d_slot[1] = p.d_parent = p.d_count = nullptr;
 	p.d_offsets = p.d_direct = p.d_albedo = p.d_throughput[0] = p.d_throughput[1] = p.d_radiance = p.d_fb = p.d_full = nullptr;
 	p.d_rays[0] = p.d_rays[1] = p.d_shadow = nullptr;
-	p.d_hits = nullptr;
+	p.d_hits = p.d_hits2 = nullptr;
 	p.d_occluded = p.d_rgb = nullptr;
 	p.cap = p.cap_full = 0;
 }
@@ -121,6 +121,7 @@ int ensure_buffers(Part &p, size_t n, size_t n_full) {
 	PART_HIP(p, hipMalloc((void **)&p.d_rays[1], c * sizeof(rtgi_ray)));
 	PART_HIP(p, hipMalloc((void **)&p.d_shadow, c * sizeof(rtgi_ray)));
 	PART_HIP(p, hipMalloc((void **)&p.d_hits, c * sizeof(rtgi_hit)));
+	PART_HIP(p, hipMalloc((void **)&p.d_hits2, c * sizeof(rtgi_hit)));
 	PART_HIP(p, hipMalloc((void **)&p.d_occluded, c));
 	PART_HIP(p, hipMalloc((void **)&p.d_rgb, f * 3));
 	p.cap = c;
@@ -186,32 +187,35 @@ int render_part(Part &p, const rtgi_frame &f, int rank, int world) {
 			p.rays += n;
 			PART_RT(p, rtgi_hip_shade_local_brdf_device(p.h, p.d_rays[0], p.d_hits, p.d_occluded, n, f.light_pos, f.light_col, p.d_radiance, st));
 		} else {
-			// a path per pixel sample: light every vertex, then follow one diffuse bounce, `bounces` times
+			// a path per pixel sample: light every vertex, then follow one diffuse bounce, `bounces` times. The shadow
+			// rays of a vertex and the rays of the next segment do not depend on each other: they are traced in ONE
+			// launch (rtgi_hip_trace_batches_device), which ends in one tail instead of two.
 			PART_RT(p, rtgi_hip_path_begin_device(p.h, n, p.d_throughput[0], p.d_slot[0], p.d_radiance, st));
+			rtgi_hit *hits[2] = {p.d_hits, p.d_hits2};
 			uint32_t m = n;
-			int cur = 0;
+			int cur = 0, hcur = 0;
 			for (uint32_t depth = 0;; ++depth) {
-				if (depth > 0) {
-					PART_RT(p, rtgi_hip_closest_hit_device(p.h, p.d_rays[cur], m, p.d_hits, nullptr, st));
-					p.rays += m;
+				PART_RT(p, rtgi_hip_shadow_rays_device(p.h, hits[hcur], m, f.light_pos, p.d_shadow, st));
+				uint32_t next = 0;
+				if (depth < f.bounces) {
+					PART_RT(p, rtgi_hip_shade_primary_device(p.h, hits[hcur], m, p.d_albedo, st));
+					// (seed: one stream of numbers per sample; keys: the pixel, so that a path does not depend on the sharding)
+					PART_RT(p, rtgi_hip_bounce_rays_keyed_device(p.h, p.d_rays[cur], hits[hcur], m, p.d_slot[cur], d_pixels,
+					                                             f.seed * 0x9E3779B1u + sample, depth + 1, p.d_rays[1 - cur], p.d_parent, p.d_count, st));
+					// the number of rays that go on is needed on the host: the next launches are sized by it
+					PART_HIP(p, hipMemcpyAsync(&next, p.d_count, 4, hipMemcpyDeviceToHost, st));
+					PART_HIP(p, hipStreamSynchronize(st));
 				}
-				PART_RT(p, rtgi_hip_shadow_rays_device(p.h, p.d_hits, m, f.light_pos, p.d_shadow, st));
-				PART_RT(p, rtgi_hip_any_hit_device(p.h, p.d_shadow, m, p.d_occluded, nullptr, st));
-				p.rays += m;
-				PART_RT(p, rtgi_hip_shade_local_brdf_device(p.h, p.d_rays[cur], p.d_hits, p.d_occluded, m, f.light_pos, f.light_col, p.d_direct, st));
+				const rtgi_batch both[2] = {{p.d_shadow, p.d_occluded, m, RTGI_BATCH_ANY_HIT}, {p.d_rays[1 - cur], hits[1 - hcur], next, RTGI_BATCH_CLOSEST_HIT}};
+				PART_RT(p, rtgi_hip_trace_batches_device(p.h, both, next ? 2 : 1, st));
+				p.rays += (uint64_t)m + next;
+				PART_RT(p, rtgi_hip_shade_local_brdf_device(p.h, p.d_rays[cur], hits[hcur], p.d_occluded, m, f.light_pos, f.light_col, p.d_direct, st));
 				PART_RT(p, rtgi_hip_path_add_device(p.h, p.d_direct, p.d_throughput[cur], p.d_slot[cur], m, p.d_radiance, st));
-				if (depth == f.bounces) break;
-				PART_RT(p, rtgi_hip_shade_primary_device(p.h, p.d_hits, m, p.d_albedo, st));
-				// (seed: one stream of numbers per sample; keys: the pixel, so that a path does not depend on the sharding)
-				PART_RT(p, rtgi_hip_bounce_rays_keyed_device(p.h, p.d_rays[cur], p.d_hits, m, p.d_slot[cur], d_pixels,
-				                                             f.seed * 0x9E3779B1u + sample, depth + 1, p.d_rays[1 - cur], p.d_parent, p.d_count, st));
-				uint32_t next = 0;  // the number of rays that go on is needed on the host: the next launches are sized by it
-				PART_HIP(p, hipMemcpyAsync(&next, p.d_count, 4, hipMemcpyDeviceToHost, st));
-				PART_HIP(p, hipStreamSynchronize(st));
 				if (next == 0) break;
 				PART_RT(p, rtgi_hip_path_extend_device(p.h, p.d_albedo, p.d_parent, next, p.d_throughput[cur], p.d_slot[cur],
 				                                       p.d_throughput[1 - cur], p.d_slot[1 - cur], st));
 				cur = 1 - cur;
+				hcur = 1 - hcur;
 				m = next;
 			}
 		}
