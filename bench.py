@@ -264,7 +264,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     device = 0 if args.one_device else local_rank
-    if world > 1:
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ  # by torch.distributed.run, whatever the world size
+    if world > 1 or launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(device)
         if args.backend == "nccl":
@@ -274,9 +275,10 @@ def main():
     elif args.gpus != 1:
         raise SystemExit("--gpus %d needs to be launched through torch.distributed.run" % args.gpus)
     torch.cuda.set_device(device)
+    grouped = dist.is_initialized()
     if args.frame:
-        frame_mode(args, world, rank, device)
-        if world > 1:
+        frame_mode(args, world, rank, device, grouped)
+        if grouped:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -295,7 +297,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -314,7 +316,7 @@ def main():
     assert torch.equal(d_hits, alg["hits"]), "timed launch and counting launch disagree"
 
     stats = torch.tensor([elapsed, float(n)], dtype=torch.float64, device="cuda:%d" % device if args.backend == "nccl" else "cpu")
-    if world > 1:
+    if grouped:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = stats.clone()
@@ -359,12 +361,12 @@ def main():
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args, w, d_hits.cpu().numpy().view(np.dtype([("t", "<f4"), ("beta", "<f4"), ("gamma", "<f4"), ("ref", "<u4")])).reshape(-1))
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def frame_mode(args, world, rank, device):
+def frame_mode(args, world, rank, device, grouped):
     """One step = one frame of `sppx` samples per pixel, path-traced (camera ray, `bounces` diffuse bounces, a shadow
     ray at every vertex) by the C++ frame loop: every rank renders its 64x64 tiles with the whole BVH on its GPU, then
     one ncclAllReduce of the framebuffer (sums and counts), all inside the timed region."""
@@ -378,7 +380,7 @@ def frame_mode(args, world, rank, device):
     uid = torch.zeros(128, dtype=torch.uint8, device=dev)
     if rank == 0:
         uid = torch.tensor(list(frame.HipRenderer.unique_id()), dtype=torch.uint8, device=dev)
-    if world > 1:
+    if grouped:
         dist.broadcast(uid, 0)
     r = frame.HipRenderer(devices=(device,), layout=args.layout, rank=rank, world=world, unique_id=bytes(uid.cpu().tolist()))
     for cmd in [c.strip() for c in args.bvh.split(";") if c.strip()]:
@@ -393,7 +395,7 @@ def frame_mode(args, world, rank, device):
 
     def barrier():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -412,7 +414,7 @@ def frame_mode(args, world, rank, device):
     assert (fb[:, 3] == args.sppx).all(), "the combined frame does not hold every sample of every pixel"
     stats = torch.tensor([elapsed, float(rays), ms_reduce], dtype=torch.float64, device=dev)
     total_rays = float(rays)
-    if world > 1:
+    if grouped:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = stats.clone()
