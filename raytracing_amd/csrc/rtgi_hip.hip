@@ -212,6 +212,7 @@ struct rtgi_hip_tracer {
 	void *pinned = nullptr, *d_pinned = nullptr;
 	HostPipe *pipe = nullptr;
 	uint32_t host_chunk = 768u << 10;  // rays per chunk of a large host batch (every chunk's launch ends in its own tail)
+	uint32_t host_lead = 256u << 10, host_lead_min = 192u << 10;  // the short first chunk: at most / batches of twice this have one
 	bool host_direct = true;           // closest_hit on host batches: the kernel writes the hit records to host memory itself
 };
 
@@ -280,6 +281,7 @@ void read_tunables(rtgi_hip_tracer *h) {
 	h->max_top_nodes = number("RTGI_HIP_TOP_NODES", 0, 1 << 30, h->max_top_nodes);
 	h->reorder = number("RTGI_HIP_REORDER", 0, 2, h->reorder);
 	h->host_chunk = (uint32_t)number("RTGI_HIP_HOST_CHUNK", 1 << 16, 1 << 30, (int)h->host_chunk);
+	h->host_lead = (uint32_t)number("RTGI_HIP_HOST_LEAD", 0, 1 << 30, (int)h->host_lead);
 	h->host_direct = number("RTGI_HIP_HOST_DIRECT", 0, 1, 1) != 0;
 }
 
@@ -772,17 +774,31 @@ int trace_host(rtgi_hip_tracer *h, const rtgi_ray *rays, uint32_t n, void *out) 
 	rc = ensure_pipe(h);
 	if (rc) return rc;
 	HostPipe &p = *h->pipe;
-	// chunks of equal size, at most host_chunk rays each; a batch that fits one chunk still gains the parallel staging
-	const uint32_t n_chunks = (n + h->host_chunk - 1) / h->host_chunk;
-	const uint32_t chunk = ((n + n_chunks - 1) / n_chunks + 63u) & ~63u;
-	const size_t out_item = ANY ? 1 : sizeof(rtgi_hit);
 	const bool rays_locked = is_page_locked(rays), out_locked = is_page_locked(out);
+	// Chunks: every chunk's launch ends in a tail of its own, so there are few. From page-locked memory a short first
+	// one (a good quarter of the batch, at most host_lead rays) gets the GPU going early and the rest follows in
+	// parts of up to 5/3 host_chunk rays, each travelling up while its predecessor is traced; from ordinary memory,
+	// where the staging copies of the host threads set the pace, equal parts of at most host_chunk rays.
+	std::vector<size_t> bounds = {0};
+	{
+		const size_t limit = rays_locked ? (size_t)h->host_chunk * 5 / 3 : h->host_chunk;
+		size_t lead = rays_locked && n >= 2 * (size_t)h->host_lead_min ? std::min<size_t>((size_t)(n * 0.28), h->host_lead) & ~(size_t)63 : 0;
+		if (lead) bounds.push_back(lead);
+		const size_t rest = n - lead, parts = (rest + limit - 1) / limit;
+		const size_t part = ((rest + parts - 1) / parts + 63u) & ~(size_t)63;
+		for (size_t at = lead + part; at < n; at += part) bounds.push_back(at);
+		bounds.push_back(n);
+	}
+	const uint32_t n_chunks = (uint32_t)bounds.size() - 1;
+	uint32_t chunk = 0;  // the largest
+	for (uint32_t k = 0; k < n_chunks; ++k) chunk = std::max<uint32_t>(chunk, (uint32_t)(bounds[k + 1] - bounds[k]));
+	const size_t out_item = ANY ? 1 : sizeof(rtgi_hit);
 	if (!rays_locked || !out_locked) {
 		rc = ensure_slots(h, chunk);
 		if (rc) return rc;
 	}
-	auto first_of = [&](uint32_t k) { return (size_t)k * chunk; };
-	auto count_of = [&](uint32_t k) { return (uint32_t)std::min<size_t>(chunk, n - first_of(k)); };
+	auto first_of = [&](uint32_t k) { return bounds[k]; };
+	auto count_of = [&](uint32_t k) { return (uint32_t)(bounds[k + 1] - bounds[k]); };
 	// results of chunk k, once they have come down into its slot, go to the caller's buffer
 	auto hand_over = [&](uint32_t k) -> int {
 		HIP_TRY(h, hipEventSynchronize(p.went_down[k % HostPipe::SLOTS]));
