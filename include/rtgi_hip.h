@@ -214,7 +214,7 @@ int rtgi_hip_shadow_rays_device(rtgi_hip_tracer *h, const rtgi_hit *d_hits, uint
 /* The part of the scene the shading stages read, given once after build(): per-vertex normals (3 floats,
  * `normal_stride` bytes apart: &scene.vertices[0].norm, 32), the triangles as passed to build() with the
  * material index as fourth uint32 (libgi/rt.h:35-38, stride 16), and one albedo per material
- * (material::albedo, libgi/material.h:54; textures are not supported). Stores, per triangle id as hits
+ * (material::albedo, libgi/material.h:54; textures: rtgi_hip_set_textures). Stores, per triangle id as hits
  * report it, the shading normal normalize(a.norm + b.norm + c.norm) of diff_geom (libgi/rt.cpp:10). */
 int rtgi_hip_set_shading(rtgi_hip_tracer *h, const void *vertex_normals, size_t normal_stride, uint32_t n_vertices,
                          const void *triangles, size_t tri_stride, uint32_t n_triangles, const float *albedo_rgb,
@@ -231,8 +231,8 @@ int rtgi_hip_shade_local_device(rtgi_hip_tracer *h, const rtgi_hit *d_hits, cons
                                 const float light_pos[3], const float light_col[3], float *d_radiance, void *stream);
 
 /* struct material, libgi/material.h:54-61, as far as local illumination reads it, and the brdf names of new_brdf
- * (libgi/material.cpp:77-102: "lambert", "phong", "layered-phong", "gtr2", "layered-gtr2"). Albedo textures are not
- * supported (`material texture drop` is the state every material is in). */
+ * (libgi/material.cpp:77-102: "lambert", "phong", "layered-phong", "gtr2", "layered-gtr2"). Albedo textures are
+ * given by rtgi_hip_set_textures. */
 enum { RTGI_BRDF_LAMBERT = 0, RTGI_BRDF_PHONG = 1, RTGI_BRDF_LAYERED_PHONG = 2, RTGI_BRDF_GTR2 = 3, RTGI_BRDF_LAYERED_GTR2 = 4 };
 typedef struct rtgi_material {
 	float albedo[3];
@@ -245,6 +245,22 @@ typedef struct rtgi_material {
  * material table given to rtgi_hip_set_shading (which sets ior 1.3, roughness 0.1, lambert), same number of
  * materials. Waits for the GPU; no rebuild needed. */
 int rtgi_hip_set_materials(rtgi_hip_tracer *h, const rtgi_material *materials, uint32_t n_materials);
+
+/* Albedo textures: material::albedo_tex (libgi/material.h:57) as diff_geom::albedo reads it (libgi/rt.cpp:27-31): a
+ * material with a texture takes its albedo from the texel at the hit's interpolated texture coordinate (diff_geom::tc,
+ * libgi/rt.cpp:11; texture::sample, libgi/scene.h:24-32: coordinates wrap, nearest texel), in every shading stage.
+ * texel[y * w + x] as in struct texture (libgi/scene.h:16-32): linear rgb, rows as the loader left them (load_image3f
+ * flips the image and raises it to the power 2.2, libgi/scene.cpp:45-68; that is the caller's business here).
+ * vertex_tc: first vertex::tc (2 floats, tc_stride bytes apart: &scene.vertices[0].tc, 32); triangles as given to
+ * rtgi_hip_build; material_texture: per material an index into `textures`, or -1 (`material texture drop`). Call
+ * after rtgi_hip_set_shading (which forgets the textures); n_textures = 0 drops them all. The data is copied. */
+typedef struct rtgi_texture {
+	const float *rgb;
+	uint32_t w, h;
+} rtgi_texture;
+int rtgi_hip_set_textures(rtgi_hip_tracer *h, const void *vertex_tc, size_t tc_stride, uint32_t n_vertices, const void *triangles,
+                          size_t tri_stride, uint32_t n_triangles, const rtgi_texture *textures, uint32_t n_textures,
+                          const int32_t *material_texture, uint32_t n_materials);
 
 /* rtgi_hip_shade_local_device with the BRDF of each hit's material (brdf::f, libgi/material.cpp:7-75): needs the
  * rays the hits belong to, for w_o = -ray.d (gi/primary-hit.cpp:45). For lambertian materials the result is

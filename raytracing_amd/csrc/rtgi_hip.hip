@@ -163,6 +163,9 @@ struct rtgi_hip_tracer {
 	float4 *d_normals = nullptr;  // shading normal and material index by reported id (set_shading)
 	float4 *d_albedo = nullptr;
 	float4 *d_matparams = nullptr;  // per material: ior, roughness, brdf kind (set_shading: 1.3, 0.1, lambert; set_materials)
+	// albedo textures (set_textures): texture coordinates by reported id, texture of each material, all texels
+	float4 *d_tex_coords = nullptr, *d_texels = nullptr;
+	uint4 *d_tex_of_material = nullptr;
 	uint32_t n_materials = 0, n_scene_triangles = 0, n_scene_vertices = 0;
 	// Launches that use the handle's scratch (ray counters, sort buffers, spill area, block counts) are ordered on
 	// the GPU even when the caller moves from one stream to another: see scratch_begin / scratch_end.
@@ -250,6 +253,14 @@ struct DeviceScope {
 	DeviceScope &operator=(const DeviceScope &) = delete;
 };
 
+void free_textures(rtgi_hip_tracer *h) {
+	if (h->d_tex_coords) (void)hipFree(h->d_tex_coords);
+	if (h->d_texels) (void)hipFree(h->d_texels);
+	if (h->d_tex_of_material) (void)hipFree(h->d_tex_of_material);
+	h->d_tex_coords = h->d_texels = nullptr;
+	h->d_tex_of_material = nullptr;
+}
+
 void free_device_tree(rtgi_hip_tracer *h) {
 	if (h->d_nodes) (void)hipFree(h->d_nodes);
 	if (h->d_tris) (void)hipFree(h->d_tris);
@@ -258,6 +269,7 @@ void free_device_tree(rtgi_hip_tracer *h) {
 	if (h->d_normals) (void)hipFree(h->d_normals);
 	if (h->d_albedo) (void)hipFree(h->d_albedo);
 	if (h->d_matparams) (void)hipFree(h->d_matparams);
+	free_textures(h);
 	h->d_corners = h->d_normals = h->d_albedo = h->d_matparams = nullptr;
 	h->n_materials = 0;
 	h->d_nodes = h->d_tris = nullptr;
@@ -1428,6 +1440,7 @@ int rtgi_hip_set_shading(rtgi_hip_tracer *h, const void *vertex_normals, size_t 
 	if (h->d_normals) (void)hipFree(h->d_normals);
 	if (h->d_albedo) (void)hipFree(h->d_albedo);
 	if (h->d_matparams) (void)hipFree(h->d_matparams);
+	free_textures(h);
 	h->d_normals = h->d_albedo = h->d_matparams = nullptr;
 	h->n_materials = 0;
 	// (material defaults of libgi/material.h:58-59: ior 1.3, roughness 0.1; brdf lambert, libgi/scene.cpp:100-102)
@@ -1465,6 +1478,63 @@ int rtgi_hip_set_materials(rtgi_hip_tracer *h, const rtgi_material *materials, u
 	return RTGI_OK;
 }
 
+int rtgi_hip_set_textures(rtgi_hip_tracer *h, const void *vertex_tc, size_t tc_stride, uint32_t n_vertices, const void *triangles,
+                          size_t tri_stride, uint32_t n_triangles, const rtgi_texture *textures, uint32_t n_textures,
+                          const int32_t *material_texture, uint32_t n_materials) {
+	if (!h) return RTGI_ERR_INVALID;
+	if (h->device < 0) return fail(h, RTGI_ERR_DEVICE, "host-only handle: needs a GPU");
+	if (!h->n_materials) return fail(h, RTGI_ERR_NOT_BUILT, "no shading data: call set_shading after build");
+	if (n_materials != h->n_materials || n_triangles != h->n_scene_triangles || n_vertices != h->n_scene_vertices)
+		return fail(h, RTGI_ERR_INVALID, "set_textures: not the scene and material table that set_shading was given");
+	DeviceScope device_scope(h->device);
+	HIP_TRY(h, device_scope.status);
+	HIP_TRY(h, hipDeviceSynchronize());  // (shading launches may still read the old tables)
+	free_textures(h);
+	if (n_textures == 0) return RTGI_OK;  // `material texture drop` for all
+	if (!vertex_tc || !triangles || !textures || !material_texture || tc_stride < 8 || tri_stride < 12)
+		return fail(h, RTGI_ERR_INVALID, "set_textures: null array or strides below 8 / 12 bytes");
+	std::vector<uint32_t> first(n_textures);
+	size_t total = 0;
+	for (uint32_t t = 0; t < n_textures; ++t) {
+		if (!textures[t].rgb || textures[t].w == 0 || textures[t].h == 0 || textures[t].w > 32768 || textures[t].h > 32768)
+			return fail(h, RTGI_ERR_INVALID, "set_textures: empty or oversized texture");
+		first[t] = (uint32_t)total;
+		total += (size_t)textures[t].w * textures[t].h;
+		if (total > 0x7fffffffu) return fail(h, RTGI_ERR_INVALID, "set_textures: more than 2^31 texels");
+	}
+	std::vector<uint32_t> of_material((size_t)n_materials * 4, 0u);
+	for (uint32_t m = 0; m < n_materials; ++m) {
+		const int32_t t = material_texture[m];
+		if (t < 0) continue;
+		if ((uint32_t)t >= n_textures) return fail(h, RTGI_ERR_INVALID, "set_textures: texture index out of range");
+		of_material[4 * (size_t)m] = first[(size_t)t], of_material[4 * (size_t)m + 1] = textures[t].w, of_material[4 * (size_t)m + 2] = textures[t].h;
+		of_material[4 * (size_t)m + 3] = 1u;
+	}
+	const bool flat = h->cfg.layout == RTGI_LAYOUT_FLAT;
+	const uint32_t n_ids = flat ? (uint32_t)h->tree.order.size() : n_triangles;
+	std::vector<float> coords((size_t)n_ids * 8, 0.0f);
+	for (uint32_t id = 0; id < n_ids; ++id) {
+		const uint32_t src = flat ? h->tree.order[id] : id;  // hits of the flat layout name slots of the permuted list
+		uint32_t v[3];
+		memcpy(v, (const unsigned char *)triangles + (size_t)src * tri_stride, 12);
+		for (int c = 0; c < 3; ++c) {
+			if (v[c] >= n_vertices) return fail(h, RTGI_ERR_INVALID, "set_textures: vertex id out of range");
+			memcpy(&coords[(size_t)id * 8 + 2 * (size_t)c], (const unsigned char *)vertex_tc + (size_t)v[c] * tc_stride, 8);
+		}
+	}
+	std::vector<float> texels(total * 4, 0.0f);
+	for (uint32_t t = 0; t < n_textures; ++t)
+		for (size_t i = 0, n = (size_t)textures[t].w * textures[t].h; i < n; ++i)
+			memcpy(&texels[(first[t] + i) * 4], textures[t].rgb + 3 * i, 12);
+	HIP_TRY(h, hipMalloc((void **)&h->d_tex_coords, std::max<size_t>(coords.size() * sizeof(float), 32)));
+	HIP_TRY(h, hipMalloc((void **)&h->d_texels, texels.size() * sizeof(float)));
+	HIP_TRY(h, hipMalloc((void **)&h->d_tex_of_material, of_material.size() * sizeof(uint32_t)));
+	if (!coords.empty()) HIP_TRY(h, hipMemcpy(h->d_tex_coords, coords.data(), coords.size() * sizeof(float), hipMemcpyHostToDevice));
+	HIP_TRY(h, hipMemcpy(h->d_texels, texels.data(), texels.size() * sizeof(float), hipMemcpyHostToDevice));
+	HIP_TRY(h, hipMemcpy(h->d_tex_of_material, of_material.data(), of_material.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	return RTGI_OK;
+}
+
 namespace {
 int shade(rtgi_hip_tracer *h, bool local, const rtgi_ray *d_rays, const rtgi_hit *d_hits, const uint8_t *d_occluded, uint32_t n, const float *light_pos,
           const float *light_col, float *d_radiance, void *stream) {
@@ -1495,6 +1565,9 @@ int shade(rtgi_hip_tracer *h, bool local, const rtgi_ray *d_rays, const rtgi_hit
 	a.n_materials = h->n_materials;
 	a.rays = (const float4 *)d_rays;
 	a.params = h->d_matparams;
+	a.tex_coords = h->d_tex_coords;
+	a.tex_of_material = h->d_tex_of_material;
+	a.texels = h->d_texels;
 	if (local && d_rays)
 		hipLaunchKernelGGL(rtgi_dev::shade_local_brdf_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
 	else if (local)

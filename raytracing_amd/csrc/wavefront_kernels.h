@@ -232,11 +232,37 @@ struct ShadeArgs {
 	uint32_t n, n_materials;
 	const float4 *rays;       // shade_local_brdf: the rays whose hits are shaded (w_o = -d)
 	const float4 *params;     // shade_local_brdf: per material ior, roughness, brdf kind (bits)
+	// albedo textures (all optional): per reported triangle id two float4 (a.tc b.tc | c.tc 0 0); per material
+	// (first texel, w, h, 1) as integers or all zero; the texels of all textures, rgb in a float4 each
+	const float4 *tex_coords;
+	const uint4 *tex_of_material;
+	const float4 *texels;
 };
 
-__device__ __forceinline__ float4 material_albedo(const ShadeArgs &a, float4 normal) {
+// diff_geom::albedo, libgi/rt.cpp:27-31: the material's colour, or its texture at the hit's texture coordinate
+// (diff_geom::tc, libgi/rt.cpp:11, sampled like texture::sample, libgi/scene.h:24-32: wrap, nearest texel).
+__device__ __forceinline__ float4 material_albedo(const ShadeArgs &a, float4 normal, float4 hit) {
 	const uint32_t m = __float_as_uint(normal.w);
-	return m < a.n_materials ? a.albedo[m] : make_float4(0, 0, 0, 0);
+	if (m >= a.n_materials) return make_float4(0, 0, 0, 0);
+	if (a.tex_of_material) {
+		const uint4 t = a.tex_of_material[m];
+		if (t.w) {
+			const uint32_t id = __float_as_uint(hit.w);
+			const float4 ab = a.tex_coords[2 * (size_t)id], c = a.tex_coords[2 * (size_t)id + 1];
+			const float beta = hit.y, gamma = hit.z;
+			const float alpha = 1.0f - beta - gamma;
+			float u = alpha * ab.x + beta * ab.z + gamma * c.x;
+			float v = alpha * ab.y + beta * ab.w + gamma * c.y;
+			u = u - floorf(u);
+			v = v - floorf(v);
+			int x = (int)(u * (float)t.y + 0.5f);
+			int y = (int)(v * (float)t.z + 0.5f);
+			if (x == (int)t.y) x = 0;
+			if (y == (int)t.z) y = 0;
+			return a.texels[(size_t)t.x + (size_t)y * t.y + (size_t)x];
+		}
+	}
+	return a.albedo[m];
 }
 
 // primary_hit_display::sample_pixel, gi/primary-hit.cpp:16-30: the albedo of what the ray hit, else black
@@ -247,7 +273,7 @@ __global__ __launch_bounds__(256) void shade_primary_kernel(ShadeArgs a) {
 	const float4 hit = a.hits[i];
 	float4 c = make_float4(0, 0, 0, 0);
 	if (hit.x != FLT_MAX) {
-		c = material_albedo(a, a.normals[__float_as_uint(hit.w)]);
+		c = material_albedo(a, a.normals[__float_as_uint(hit.w)], hit);
 		c.w = 0.0f;
 	}
 	a.out[i] = c;
@@ -274,7 +300,7 @@ __global__ __launch_bounds__(256) void shade_local_kernel(ShadeArgs a) {
 		const float qx = ns.x * wx, qy = ns.y * wy, qz = ns.z * wz;
 		if (qx + qy + qz > 0.0f) {  // same_hemisphere(w_i, ns), libgi/util.h:115-117
 			const float one_over_pi = (float)(1.0 / 3.14159265358979323846);  // libgi/rt.h:15
-			const float4 alb = material_albedo(a, ns);
+			const float4 alb = material_albedo(a, ns, hit);
 			const float dd = d * d;
 			c.x = a.power[0] * (one_over_pi * alb.x) / dd;
 			c.y = a.power[1] * (one_over_pi * alb.y) / dd;
@@ -385,7 +411,7 @@ __global__ __launch_bounds__(256) void shade_local_brdf_kernel(ShadeArgs a) {
 		hit_point(a.corners, hit, x, y, z, A, B, C);
 		const float4 ns = a.normals[__float_as_uint(hit.w)];
 		const uint32_t m = __float_as_uint(ns.w);
-		const float4 alb = material_albedo(a, ns);
+		const float4 alb = material_albedo(a, ns, hit);
 		const float4 par = m < a.n_materials ? a.params[m] : make_float4(1.3f, 0.1f, 0.0f, 0.0f);
 		const uint32_t kind = __float_as_uint(par.z);
 		const float lx = a.light[0] - x, ly = a.light[1] - y, lz = a.light[2] - z;

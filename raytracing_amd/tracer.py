@@ -33,10 +33,14 @@ EXPORTS = [
     "rtgi_hip_pixel_offsets_device", "rtgi_hip_pixel_offsets_pixels_device", "rtgi_hip_camera_rays_pixels_device",
     "rtgi_hip_bounce_rays_keyed_device", "rtgi_hip_path_begin_device", "rtgi_hip_path_add_device", "rtgi_hip_path_extend_device",
     "rtgi_hip_framebuffer_scatter_device", "rtgi_hip_framebuffer_sums_device", "rtgi_hip_framebuffer_accumulate_device", "rtgi_hip_shadow_rays_device", "rtgi_hip_bounce_rays_device", "rtgi_hip_set_shading",
-    "rtgi_hip_shade_primary_device", "rtgi_hip_shade_local_device", "rtgi_hip_set_materials", "rtgi_hip_shade_local_brdf_device", "rtgi_hip_framebuffer_add_device",
+    "rtgi_hip_shade_primary_device", "rtgi_hip_shade_local_device", "rtgi_hip_set_materials", "rtgi_hip_set_textures", "rtgi_hip_shade_local_brdf_device", "rtgi_hip_framebuffer_add_device",
     "rtgi_hip_framebuffer_rgb8_device", "rtgi_hip_profile_begin", "rtgi_hip_profile_end", "rtgi_hip_profile_work",
     "rtgi_hip_last_error",
 ]
+
+
+class Texture(C.Structure):  # rtgi_texture
+    _fields_ = [("rgb", C.c_void_p), ("w", C.c_uint32), ("h", C.c_uint32)]
 
 
 class RtgiHipError(RuntimeError):
@@ -103,6 +107,7 @@ def lib():
         L.rtgi_hip_shade_primary_device.argtypes = [vp, vp, u32, vp, vp]
         L.rtgi_hip_shade_local_device.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp]
         L.rtgi_hip_set_materials.argtypes = [vp, vp, u32]
+        L.rtgi_hip_set_textures.argtypes = [vp, vp, sz, u32, vp, sz, u32, vp, u32, vp, u32]
         L.rtgi_hip_shade_local_brdf_device.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, vp]
         L.rtgi_hip_framebuffer_add_device.argtypes = [vp, vp, vp, u32, vp]
         L.rtgi_hip_framebuffer_rgb8_device.argtypes = [vp, vp, u32, u32, vp, vp]
@@ -332,6 +337,19 @@ class HipBvhTracer:
         rec["albedo"], rec["ior"], rec["roughness"] = albedo, ior, roughness
         rec["brdf"] = [BRDF[b] for b in brdf]
         self._check(lib().rtgi_hip_set_materials(self._h, rec.ctypes.data, n))
+
+    def set_textures(self, tex_coords, tri, textures, material_texture):
+        """Albedo textures (libgi/rt.cpp:27-31): tex_coords (nv, 2) per vertex, tri as given to build(), textures a list
+        of (h, w, 3) float32 arrays (texel[y, x], linear rgb), material_texture (n_materials,) texture index or -1."""
+        tc = np.ascontiguousarray(tex_coords, dtype=np.float32)
+        tri = np.ascontiguousarray(tri, dtype=np.uint32)
+        arrays = [np.ascontiguousarray(t, dtype=np.float32) for t in textures]
+        rec = (Texture * max(len(arrays), 1))()
+        for i, t in enumerate(arrays):
+            rec[i] = Texture(t.ctypes.data, t.shape[1], t.shape[0])
+        mt = np.ascontiguousarray(material_texture, dtype=np.int32)
+        self._check(lib().rtgi_hip_set_textures(self._h, tc.ctypes.data, 8, len(tc), tri.ctypes.data, 12, len(tri), rec, len(arrays),
+                                                mt.ctypes.data, len(mt)))
 
     def shade_local_brdf_device(self, d_rays, d_hits, d_occluded, light_pos, light_col, stream=None):
         """shade_local_device with each material's own BRDF (libgi/material.cpp:7-75); needs the rays for w_o."""

@@ -134,6 +134,39 @@ def shading_normals(normals, tri):
     return (s * (f(1.0) / np.sqrt(sq, dtype=f))[:, None]).astype(f)
 
 
+def texture_albedo(tex_coords, tri, hits, texture):
+    """diff_geom::albedo through a texture (libgi/rt.cpp:11, 27-31; texture::sample, libgi/scene.h:24-32): texture
+    coordinate interpolated with the hit's barycentrics, wrapped, nearest texel. tri: the triangles hit ids index;
+    texture: (h, w, 3) float32. Returns (n, 3) for the hits given (all must be hits)."""
+    f = np.float32
+    tc = np.asarray(tex_coords, f)[tri[hits["ref"]]]  # (n, 3, 2)
+    beta, gamma = hits["beta"].astype(f), hits["gamma"].astype(f)
+    alpha = ((f(1.0) - beta) - gamma).astype(f)
+    uv = ((alpha[:, None] * tc[:, 0] + beta[:, None] * tc[:, 1]).astype(f) + gamma[:, None] * tc[:, 2]).astype(f)
+    uv = (uv - np.floor(uv)).astype(f)
+    th, tw = texture.shape[0], texture.shape[1]
+    x = (uv[:, 0] * f(tw) + f(0.5)).astype(f).astype(np.int64)
+    y = (uv[:, 1] * f(th) + f(0.5)).astype(f).astype(np.int64)
+    x[x == tw] = 0
+    y[y == th] = 0
+    return np.asarray(texture, f)[y, x]
+
+
+def albedo_of_hits(hits, material_id, albedo, tex_coords=None, tri=None, textures=None, material_texture=None):
+    """Albedo per valid hit: the material's colour, or its texture's texel where it has one."""
+    valid = hits["t"] != FLT_MAX
+    hv = hits[valid]
+    mid = np.asarray(material_id)[hv["ref"]]
+    out = np.asarray(albedo, np.float32)[mid].copy()
+    if textures:
+        mt = np.asarray(material_texture)[mid]
+        for k, tex in enumerate(textures):
+            sel = mt == k
+            if sel.any():
+                out[sel] = texture_albedo(tex_coords, tri, hv[sel], tex)
+    return valid, out
+
+
 def shade_primary(hits, material_id, albedo):
     """primary_hit_display::sample_pixel, gi/primary-hit.cpp:16-30: albedo of the hit triangle, black for a miss."""
     out = np.zeros((len(hits), 4), np.float32)
@@ -142,7 +175,7 @@ def shade_primary(hits, material_id, albedo):
     return out
 
 
-def shade_local(pos, tri, ns, material_id, albedo, hits, occluded, light_pos, light_col):
+def shade_local(pos, tri, ns, material_id, albedo, hits, occluded, light_pos, light_col, albedo_fn=None):
     """local_illumination::sample_pixel, gi/primary-hit.cpp:32-57, with the lambertian BRDF
     (libgi/material.cpp:17-20) and pointlight::power = 4 pi col (libgi/scene.cpp:216-218)."""
     f = np.float32
@@ -157,7 +190,7 @@ def shade_local(pos, tri, ns, material_id, albedo, hits, occluded, light_pos, li
     n = ns[hv["ref"]]
     facing = ((n[:, 0] * w_i[:, 0] + n[:, 1] * w_i[:, 1]) + n[:, 2] * w_i[:, 2]) > 0
     power = (f(4) * PI) * np.asarray(light_col, f)
-    alb = np.asarray(albedo, f)[np.asarray(material_id)[hv["ref"]]]
+    alb = np.asarray(albedo, f)[np.asarray(material_id)[hv["ref"]]] if albedo_fn is None else albedo_fn(hv)
     rad = (power[None, :] * (ONE_OVER_PI * alb)) / (d * d)[:, None]
     rad[~facing] = 0
     out[lit, 0:3] = rad
@@ -260,7 +293,7 @@ def brdf_f(kind, n, w_o, w_i, alb, ior, roughness):
     return out
 
 
-def shade_local_brdf(pos, tri, ns, material_id, materials, rays, hits, occluded, light_pos, light_col):
+def shade_local_brdf(pos, tri, ns, material_id, materials, rays, hits, occluded, light_pos, light_col, albedo_fn=None):
     """shade_local with each hit material's own BRDF. materials: dict(albedo (n, 3), ior, roughness, kind); rays: the
     (n, 8) rays of the hits (w_o = -d, gi/primary-hit.cpp:45)."""
     f = np.float32
@@ -273,7 +306,8 @@ def shade_local_brdf(pos, tri, ns, material_id, materials, rays, hits, occluded,
     w_i = (to_light * (f(1.0) / d)[:, None]).astype(f)
     w_o = (-np.asarray(rays, f)[lit, 3:6]).astype(f)
     mid = np.asarray(material_id)[hv["ref"]]
-    fr = brdf_f(np.asarray(materials["kind"])[mid], ns[hv["ref"]], w_o, w_i, np.asarray(materials["albedo"], f)[mid],
+    alb = np.asarray(materials["albedo"], f)[mid] if albedo_fn is None else albedo_fn(hv)
+    fr = brdf_f(np.asarray(materials["kind"])[mid], ns[hv["ref"]], w_o, w_i, alb,
                 np.asarray(materials["ior"], f)[mid], np.asarray(materials["roughness"], f)[mid])
     power = (f(4) * PI) * np.asarray(light_col, f)
     with np.errstate(all="ignore"):

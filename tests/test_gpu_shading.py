@@ -144,6 +144,55 @@ def test_brdfs_against_their_host_statement():
         t.set_materials(s["albedo"][:-1], np.ones(nm - 1), np.ones(nm - 1), ["lambert"] * (nm - 1))
 
 
+def test_albedo_textures():
+    """Materials with a texture take their albedo from it (diff_geom::albedo, libgi/rt.cpp:27-31; texture::sample,
+    libgi/scene.h:24-32) in every shading stage, bit for bit like the numpy statement; dropping the textures brings
+    the material colours back."""
+    import torch
+    s = _scene()
+    w, h = 480, 270
+    rs = np.random.RandomState(11)
+    tex_coords = rs.uniform(-1.5, 2.5, (len(s["pos"]), 2)).astype(np.float32)  # beyond [0, 1): wraps
+    textures = [rs.uniform(0, 1, (23, 37, 3)).astype(np.float32), rs.uniform(0, 1, (64, 64, 3)).astype(np.float32)]
+    nm = len(s["albedo"])
+    material_texture = np.array([(k % 3) - 1 for k in range(nm)], np.int32)  # -1, 0, 1, -1, ...
+    for layout in ("flat", "indexed"):
+        t = tracer.HipBvhTracer(layout=layout)
+        t.build(s["pos"], s["tri"])
+        t.set_shading(s["normals"], s["tri"], s["material_id"], s["albedo"])
+        order = t.triangle_order() if layout == "flat" else np.arange(len(s["tri"]))
+        tri, mat = s["tri"][order], s["material_id"][order]
+        ns = wavefront.shading_normals(s["normals"], tri)
+        d_rays = t.camera_rays_device(CAM["cam_dir"], CAM["cam_pos"], CAM["cam_up"], 65.0, w, h)
+        d_hits = torch.empty((w * h, 4), dtype=torch.float32, device="cuda")
+        t.closest_hit_device(d_rays, d_hits)
+        d_occ = torch.zeros(w * h, dtype=torch.uint8, device="cuda")
+        rays, hits, occ = d_rays.cpu().numpy(), _hits_of(d_hits), d_occ.cpu().numpy()
+        plain = t.shade_primary_device(d_hits).cpu().numpy()
+        t.set_textures(tex_coords, s["tri"], textures, material_texture)
+
+        def albedo_fn(hv):
+            return wavefront.albedo_of_hits(hv, mat, s["albedo"], tex_coords, tri, textures, material_texture)[1]
+        valid, alb = wavefront.albedo_of_hits(hits, mat, s["albedo"], tex_coords, tri, textures, material_texture)
+        want = np.zeros((w * h, 4), np.float32)
+        want[valid, 0:3] = alb
+        got = t.shade_primary_device(d_hits).cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), layout
+        assert not np.array_equal(got, plain)  # textured materials are in view
+        want_l = wavefront.shade_local(s["pos"], tri, ns, mat, s["albedo"], hits, occ, LIGHT_POS, LIGHT_COL, albedo_fn=albedo_fn)
+        got_l = t.shade_local_device(d_hits, d_occ, LIGHT_POS, LIGHT_COL).cpu().numpy()
+        assert np.array_equal(got_l.view(np.uint32), want_l.view(np.uint32)), layout
+        mats = dict(albedo=s["albedo"], ior=np.full(nm, 1.7, np.float32), roughness=np.full(nm, 0.2, np.float32), kind=np.full(nm, 3))
+        t.set_materials(mats["albedo"], mats["ior"], mats["roughness"], ["gtr2"] * nm)
+        want_b = wavefront.shade_local_brdf(s["pos"], tri, ns, mat, mats, rays, hits, occ, LIGHT_POS, LIGHT_COL, albedo_fn=albedo_fn)
+        got_b = t.shade_local_brdf_device(d_rays, d_hits, d_occ, LIGHT_POS, LIGHT_COL).cpu().numpy()
+        assert np.array_equal(got_b.view(np.uint32), want_b.view(np.uint32)), layout
+        t.set_textures(tex_coords, s["tri"], [], material_texture)  # `material texture drop` for all
+        assert np.array_equal(t.shade_primary_device(d_hits).cpu().numpy(), plain)
+        with pytest.raises(tracer.RtgiHipError):
+            t.set_textures(tex_coords, s["tri"], textures, np.full(nm, 2, np.int32))  # no such texture
+
+
 def test_shading_argument_checks():
     import torch
     s = _scene()
