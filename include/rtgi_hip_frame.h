@@ -93,6 +93,12 @@ int rtgi_hip_renderer_build(rtgi_hip_renderer *r, const void *vertices, size_t v
  * GPU. The frames' shading is brdf::f of each hit's material (libgi/material.cpp:7-75). */
 int rtgi_hip_renderer_set_materials(rtgi_hip_renderer *r, const rtgi_material *materials, uint32_t n_materials);
 
+/* `material texture <file> | drop` and the textures `load` finds (libgi/scene.cpp:128-134, driver/interaction.cpp:290-302):
+ * rtgi_hip_set_textures on every GPU, same arguments (the scene arrays are those given to rtgi_hip_renderer_build). */
+int rtgi_hip_renderer_set_textures(rtgi_hip_renderer *r, const void *vertex_tc, size_t tc_stride, uint32_t n_vertices, const void *triangles,
+                                   size_t tri_stride, uint32_t n_triangles, const rtgi_texture *textures, uint32_t n_textures,
+                                   const int32_t *material_texture, uint32_t n_materials);
+
 /* `run`. framebuffer: w*h float4 (mean rgb, sample count) like rc->framebuffer.color, or NULL; rgb8: 3*w*h bytes like
  * framebuffer::png (top row first), or NULL; stats: or NULL. */
 int rtgi_hip_renderer_render(rtgi_hip_renderer *r, const rtgi_frame *frame, float *framebuffer, uint8_t *rgb8,

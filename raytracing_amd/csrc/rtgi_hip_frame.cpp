@@ -401,6 +401,18 @@ int rtgi_hip_renderer_set_materials(rtgi_hip_renderer *r, const rtgi_material *m
 	return RTGI_OK;
 }
 
+int rtgi_hip_renderer_set_textures(rtgi_hip_renderer *r, const void *vertex_tc, size_t tc_stride, uint32_t n_vertices, const void *triangles,
+                                   size_t tri_stride, uint32_t n_triangles, const rtgi_texture *textures, uint32_t n_textures,
+                                   const int32_t *material_texture, uint32_t n_materials) {
+	if (!r) return RTGI_ERR_INVALID;
+	for (Part &p : r->parts) {
+		const int rc = rtgi_hip_set_textures(p.h, vertex_tc, tc_stride, n_vertices, triangles, tri_stride, n_triangles, textures, n_textures,
+		                                     material_texture, n_materials);
+		if (rc < 0) return fail(r, rc, rtgi_hip_last_error(p.h));
+	}
+	return RTGI_OK;
+}
+
 int rtgi_hip_renderer_render(rtgi_hip_renderer *r, const rtgi_frame *frame, float *framebuffer, uint8_t *rgb8, rtgi_frame_stats *stats) {
 	if (!r) return RTGI_ERR_INVALID;
 	if (int rc = check_frame(r, frame)) return rc;

@@ -13,8 +13,8 @@
 //
 // `raytracer hip [indexed] [esc] [devices N | devices a,b,...]` selects this backend; the reference's own names
 // (`seq`, `naive-bvh`, `bbvh [indexed] [esc]`) are accepted and create the same GPU tracer with the layout asked for,
-// so that the reference's scripts run unchanged. Host-side only: OBJ/MTL reading, the material table and the PNG file
-// (the reference uses assimp, MagickWand and png++, none of which this program needs).
+// so that the reference's scripts run unchanged. Host-side only: OBJ/MTL reading, PNG textures, the material table and
+// the PNG file (the reference uses assimp, MagickWand and png++, none of which this program needs; zlib inflates).
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
@@ -29,6 +29,8 @@
 #include <sstream>
 #include <string>
 #include <vector>
+
+#include <zlib.h>
 
 #include "rtgi_hip_frame.h"
 
@@ -52,7 +54,14 @@ struct Material {
 	vec3 albedo, emissive;
 	float ior = 1.3f, roughness = 0.1f;
 	uint32_t brdf = RTGI_BRDF_LAMBERT;
-	std::string texture;  // named by the file; not loaded (no image reader here): the albedo colour is used
+	int texture = -1;          // index into Scene::textures, -1: none (`material texture drop`)
+	std::string texture_path;  // as named by the material library or the `material texture` command
+};
+// struct texture, libgi/scene.h:16-32
+struct Texture {
+	std::string path;
+	unsigned w = 0, h = 0;
+	std::vector<float> texel;  // rgb, texel[3 * (y * w + x)]
 };
 struct Object {
 	std::string name;
@@ -67,6 +76,7 @@ int brdf_by_name(const std::string &n) {
 }
 
 struct Scene {
+	std::vector<Texture> textures;
 	std::vector<Vertex> vertices;
 	std::vector<Triangle> triangles;
 	std::vector<Material> materials;
@@ -89,10 +99,95 @@ std::string dir_of(const std::string &path) {
 	return k == std::string::npos ? std::string() : path.substr(0, k + 1);
 }
 
+// ---- PNG reading (what the reference does through MagickWand): 8- or 16-bit grey, rgb, palette, with or without
+// alpha, not interlaced; zlib does the inflating ----
+bool read_png(const std::string &path, unsigned &w, unsigned &h, std::vector<float> &rgb01, std::string &err) {
+	std::ifstream in(path, std::ios::binary);
+	if (!in) return err = "cannot open " + path, false;
+	std::vector<unsigned char> file((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+	static const unsigned char magic[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+	if (file.size() < 8 || memcmp(file.data(), magic, 8) != 0) return err = path + " is not a PNG file (the only image format read here)", false;
+	auto be32 = [&](size_t at) { return ((uint32_t)file[at] << 24) | ((uint32_t)file[at + 1] << 16) | ((uint32_t)file[at + 2] << 8) | file[at + 3]; };
+	unsigned depth = 0, type = 0, interlace = 0;
+	std::vector<unsigned char> idat, palette;
+	for (size_t at = 8; at + 12 <= file.size();) {
+		const uint32_t len = be32(at);
+		if (at + 12 + (size_t)len > file.size()) return err = path + ": truncated chunk", false;
+		const std::string kind((const char *)&file[at + 4], 4);
+		const unsigned char *data = &file[at + 8];
+		if (kind == "IHDR" && len >= 13) {
+			w = be32(at + 8), h = be32(at + 12);
+			depth = data[8], type = data[9], interlace = data[12];
+		} else if (kind == "PLTE")
+			palette.assign(data, data + len);
+		else if (kind == "IDAT")
+			idat.insert(idat.end(), data, data + len);
+		else if (kind == "IEND")
+			break;
+		at += 12 + (size_t)len;
+	}
+	const unsigned channels = type == 0 ? 1 : type == 2 ? 3 : type == 3 ? 1 : type == 4 ? 2 : type == 6 ? 4 : 0;
+	if (!w || !h || w > 32768 || h > 32768 || !channels || interlace || (depth != 8 && depth != 16) || (type == 3 && depth != 8))
+		return err = path + ": unsupported kind of PNG (8 or 16 bits per channel, not interlaced)", false;
+	const size_t bpp = channels * depth / 8, stride = (size_t)w * bpp;
+	std::vector<unsigned char> raw((stride + 1) * h);
+	uLongf got = (uLongf)raw.size();
+	if (uncompress(raw.data(), &got, idat.data(), (uLong)idat.size()) != Z_OK || got != raw.size()) return err = path + ": damaged image data", false;
+	std::vector<unsigned char> prev(stride, 0), row(stride);
+	rgb01.assign((size_t)w * h * 3, 0.0f);
+	for (unsigned y = 0; y < h; ++y) {
+		const unsigned char *src = &raw[(stride + 1) * y];
+		const unsigned filter = src[0];
+		for (size_t i = 0; i < stride; ++i) {
+			const int a = i >= bpp ? row[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+			int v = src[1 + i];
+			if (filter == 1) v += a;
+			else if (filter == 2) v += b;
+			else if (filter == 3) v += (a + b) / 2;
+			else if (filter == 4) {
+				const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+				v += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+			} else if (filter != 0)
+				return err = path + ": damaged image data", false;
+			row[i] = (unsigned char)v;
+		}
+		for (unsigned x = 0; x < w; ++x) {
+			float *o = &rgb01[((size_t)y * w + x) * 3];
+			auto sample = [&](unsigned ch) { return depth == 8 ? row[x * bpp + ch] / 255.0 : (row[x * bpp + 2 * ch] * 256 + row[x * bpp + 2 * ch + 1]) / 65535.0; };
+			if (type == 3) {
+				const size_t k = (size_t)row[x] * 3;
+				for (int ch = 0; ch < 3; ++ch) o[ch] = k + 2 < palette.size() ? (float)(palette[k + ch] / 255.0) : 0.0f;
+			} else if (channels <= 2)
+				o[0] = o[1] = o[2] = (float)sample(0);
+			else
+				for (unsigned ch = 0; ch < 3; ++ch) o[ch] = (float)sample(ch);
+		}
+		prev = row;
+	}
+	return true;
+}
+
+// load_image3f, libgi/scene.cpp:45-68: rows flipped (MagickFlipImage), values to the power 2.2. Returns the index of
+// the texture in `textures` (a file already loaded is shared), or -1 with `err` set.
+int load_image3f(std::vector<Texture> &textures, const std::string &path, std::string &err) {
+	for (size_t i = 0; i < textures.size(); ++i)
+		if (textures[i].path == path) return (int)i;
+	Texture t;
+	std::vector<float> img;
+	if (!read_png(path, t.w, t.h, img, err)) return -1;
+	t.path = path;
+	t.texel.resize(img.size());
+	for (unsigned y = 0; y < t.h; ++y)
+		for (size_t i = 0; i < (size_t)t.w * 3; ++i) t.texel[(size_t)y * t.w * 3 + i] = std::pow(img[(size_t)(t.h - 1 - y) * t.w * 3 + i], 2.2f);
+	textures.push_back(std::move(t));
+	return (int)textures.size() - 1;
+}
+
 // The material library of an OBJ file: what scene::add reads through assimp (libgi/scene.cpp:104-139): Kd or, if it
 // is black, Ks as albedo, to the power 2.2; Ke; Ns as roughness (roughness_from_exponent, libgi/material.h:12-14);
 // Ni as ior with 1.0 replaced by 1.3.
-void load_mtl(const std::string &path, const std::string &prefix, uint32_t default_brdf, std::vector<Material> &out, std::map<std::string, uint32_t> &ids) {
+void load_mtl(const std::string &path, const std::string &prefix, uint32_t default_brdf, std::vector<Material> &out, std::map<std::string, uint32_t> &ids,
+              std::vector<Texture> &textures) {
 	std::ifstream in(path);
 	if (!in) {
 		std::cerr << "WARN: cannot open material library " << path << std::endl;
@@ -139,7 +234,12 @@ void load_mtl(const std::string &path, const std::string &prefix, uint32_t defau
 		m.albedo = {std::pow(base.x, 2.2f), std::pow(base.y, 2.2f), std::pow(base.z, 2.2f)};
 		m.emissive = r.ke;
 		m.brdf = default_brdf;
-		m.texture = r.tex;
+		if (!r.tex.empty()) {  // libgi/scene.cpp:128-134 (there a texture that cannot be read ends the program)
+			m.texture_path = dir_of(path) + r.tex;
+			std::string err;
+			m.texture = load_image3f(textures, m.texture_path, err);
+			if (m.texture < 0) std::cerr << "note: texture of material " << m.name << " not loaded (" << err << "): its albedo colour is used" << std::endl;
+		}
 		ids[r.name] = (uint32_t)out.size();
 		out.push_back(m);
 	}
@@ -182,7 +282,7 @@ std::string load_obj(Scene &scene, const std::string &path, const std::string &n
 		} else if (key == "mtllib") {
 			std::string file;
 			ls >> file;
-			load_mtl(dir_of(path) + file, name, scene.default_brdf, scene.materials, mtl_ids);
+			load_mtl(dir_of(path) + file, name, scene.default_brdf, scene.materials, mtl_ids, scene.textures);
 		} else if (key == "usemtl") {
 			std::string m;
 			ls >> m;
@@ -258,10 +358,7 @@ std::string load_obj(Scene &scene, const std::string &path, const std::string &n
 			}
 		}
 	}
-	for (size_t m = material_offset; m < scene.materials.size(); ++m)
-		if (!scene.materials[m].texture.empty())
-			std::cerr << "note: texture " << scene.materials[m].texture << " of material " << scene.materials[m].name
-			          << " is not loaded (no image reader): its albedo colour is used" << std::endl;
+	(void)material_offset;
 	return "";
 }
 
@@ -338,6 +435,7 @@ struct Repl {
 	// what `run` checks (repl_update_checks, driver/interaction.h)
 	int cmdid = 0, scene_touched_at = 0, tracer_touched_at = 0, accel_touched_at = 0;
 	int errors = 0;
+	bool textures_pushed = false;
 	std::map<std::string, std::pair<double, unsigned>> timers;  // `stats print`
 
 	~Repl() {
@@ -353,6 +451,25 @@ struct Repl {
 		}
 		if (rtgi_hip_renderer_set_materials(renderer, m.data(), (uint32_t)m.size()) < 0)
 			std::cerr << "materials: " << rtgi_hip_renderer_last_error(renderer) << std::endl;
+		// the textures in use, and which material uses which
+		std::vector<rtgi_texture> tex;
+		std::vector<int32_t> of_material(m.size(), -1), slot(scene.textures.size(), -1);
+		for (size_t i = 0; i < m.size(); ++i) {
+			const int t = scene.materials[i].texture;
+			if (t < 0) continue;
+			if (slot[(size_t)t] < 0) {
+				slot[(size_t)t] = (int32_t)tex.size();
+				tex.push_back({scene.textures[(size_t)t].texel.data(), scene.textures[(size_t)t].w, scene.textures[(size_t)t].h});
+			}
+			of_material[i] = slot[(size_t)t];
+		}
+		if (!tex.empty() || textures_pushed) {
+			if (rtgi_hip_renderer_set_textures(renderer, scene.vertices[0].tc, sizeof(Vertex), (uint32_t)scene.vertices.size(), scene.triangles.data(),
+			                                   sizeof(Triangle), (uint32_t)scene.triangles.size(), tex.data(), (uint32_t)tex.size(), of_material.data(),
+			                                   (uint32_t)of_material.size()) < 0)
+				std::cerr << "textures: " << rtgi_hip_renderer_last_error(renderer) << std::endl;
+			textures_pushed = !tex.empty();
+		}
 	}
 
 	std::string commit() {
@@ -644,10 +761,15 @@ void Repl::loop(std::istream &infile, bool prompt) {
 			} else if (command == "texture") {
 				in >> cmd;
 				check_in_complete("Expected a single (no whitespace) string value");
+				// (the textures stay around: other materials might still use them, driver/interaction.cpp:293-294)
 				if (cmd == "drop")
-					mat->texture.clear();
-				else
-					error("Textures are not supported by this backend (only 'material texture drop')");
+					mat->texture = -1;
+				else {
+					std::string err;
+					const int t = load_image3f(scene.textures, cmd, err);
+					if (t < 0) error(err);
+					mat->texture = t, mat->texture_path = cmd;
+				}
 			} else if (command == "brdf") {
 				in >> cmd;
 				check_in_complete("Expected a single (no whitespace) string value");
@@ -657,7 +779,7 @@ void Repl::loop(std::istream &infile, bool prompt) {
 			} else if (command == "show") {
 				check_in_complete("Does not take further arguments");
 				std::cout << "albedo     " << mat->albedo << std::endl;
-				std::cout << "albedo-tex " << (mat->texture.empty() ? std::string("none") : mat->texture + " (not loaded)") << std::endl;
+				std::cout << "albedo-tex " << (mat->texture < 0 ? std::string("none") : scene.textures[(size_t)mat->texture].path) << std::endl;
 				std::cout << "emissive   " << mat->emissive << std::endl;
 				std::cout << "roughness  " << mat->roughness << std::endl;
 				std::cout << "ior        " << mat->ior << std::endl;

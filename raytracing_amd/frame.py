@@ -21,7 +21,7 @@ SHARDING = {"tiles": 0, "samples": 1}
 # every symbol include/rtgi_hip_frame.h declares
 EXPORTS = [
     "rtgi_hip_renderer_create", "rtgi_hip_renderer_unique_id", "rtgi_hip_renderer_create_rank", "rtgi_hip_renderer_destroy", "rtgi_hip_renderer_device_count", "rtgi_hip_renderer_handle",
-    "rtgi_hip_renderer_interprete", "rtgi_hip_renderer_build", "rtgi_hip_renderer_set_materials", "rtgi_hip_renderer_render", "rtgi_hip_renderer_last_error",
+    "rtgi_hip_renderer_interprete", "rtgi_hip_renderer_build", "rtgi_hip_renderer_set_materials", "rtgi_hip_renderer_set_textures", "rtgi_hip_renderer_render", "rtgi_hip_renderer_last_error",
 ]
 
 
@@ -65,6 +65,7 @@ def lib():
         L.rtgi_hip_renderer_interprete.argtypes = [vp, cp, cp]
         L.rtgi_hip_renderer_build.argtypes = [vp, vp, sz, u32, vp, sz, u32, vp, u32]
         L.rtgi_hip_renderer_set_materials.argtypes = [vp, vp, u32]
+        L.rtgi_hip_renderer_set_textures.argtypes = [vp, vp, sz, u32, vp, sz, u32, vp, u32, vp, u32]
         L.rtgi_hip_renderer_render.argtypes = [vp, C.POINTER(Frame), vp, vp, C.POINTER(FrameStats)]
         L.rtgi_hip_renderer_last_error.argtypes = [vp]
         L.rtgi_hip_renderer_last_error.restype = cp

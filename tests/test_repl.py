@@ -90,6 +90,8 @@ def test_every_command_parses(tmp_path):
     ("material roughness 0.5\n", "No material selected"),
     ("load render-data/tri.obj\nmaterial select nothing\n", "No material called 'nothing'"),
     ("default-brdf velvet\n", "No such brdf defined: velvet"),
+    ("load render-data/tri.obj\nmaterial select tri\nmaterial texture no-such.png\n", "cannot open no-such.png"),
+    ("load render-data/tri.obj\nmaterial select tri\nmaterial texture render-data/tri.obj\n", "is not a PNG file"),
     ("pointlight at 1 2 3\n", "poinlight [replace] pos x y z col x y z"),
     ("sppx many\n", "positive integral value"),
     ("resolution 640\n", "requires 2 integral values"),
