@@ -446,6 +446,9 @@ public:
 		                              sizeof(s->triangles[0]), (uint32_t)s->triangles.size(), albedo.data(), (uint32_t)(albedo.size() / 3)));
 		n_materials = (uint32_t)(albedo.size() / 3);
 		if (!m.empty()) set_materials(m);
+		built_triangles.clear();
+		if (!indexed) built_triangles.assign(s->triangles.begin(), s->triangles.end());  // the list as built: set_textures wants that one
+		push_textures(s);
 		if (!indexed) {  // commit_shuffled_triangles, rt/bbvh-base/bvh2.cpp:172-180
 			rtgi_hip_tracer *h = rtgi_hip_renderer_handle(r, 0);
 			std::vector<uint32_t> order(rtgi_hip_num_index(h));
@@ -466,6 +469,7 @@ public:
 	void refresh_materials() {
 		std::vector<hip_material> m = materials_of(this->scene);
 		if (!m.empty()) set_materials(m);
+		push_textures(this->scene);
 	}
 	bool interprete(const std::string &command, std::istringstream &in) override {
 		std::string rest;
@@ -508,9 +512,35 @@ private:
 		}
 		return m;
 	}
+	// material::albedo_tex (libgi/material.h:57): the textures in use and which material uses which
+	void push_textures(rtgi_hip::scene *s) {
+		std::vector<rtgi_texture> tex;
+		std::vector<const ::texture *> seen;
+		std::vector<int32_t> of_material(s->materials.size(), -1);
+		for (size_t i = 0; i < s->materials.size(); ++i) {
+			const ::texture *t = s->materials[i].albedo_tex;
+			if (!t) continue;
+			size_t k = 0;
+			while (k < seen.size() && seen[k] != t) ++k;
+			if (k == seen.size()) {
+				seen.push_back(t);
+				tex.push_back(rtgi_texture{&t->texel[0].x, t->w, t->h});
+			}
+			of_material[i] = (int32_t)k;
+		}
+		if (tex.empty() && !textures_pushed) return;
+		const triangle *tris = built_triangles.empty() ? &s->triangles[0] : built_triangles.data();  // (flat: before the permutation)
+		check(rtgi_hip_renderer_set_textures(r, &s->vertices[0].tc, sizeof(s->vertices[0]), (uint32_t)s->vertices.size(), &tris[0].a,
+		                                     sizeof(triangle), (uint32_t)s->triangles.size(), tex.data(), (uint32_t)tex.size(),
+		                                     of_material.data(), (uint32_t)of_material.size()));
+		textures_pushed = !tex.empty();
+	}
 #else
 	static std::vector<hip_material> materials_of(rtgi_hip::scene *) { return {}; }
+	void push_textures(rtgi_hip::scene *) {}
 #endif
+	bool textures_pushed = false;
+	std::vector<triangle> built_triangles;
 	rtgi_hip_renderer *r = nullptr;
 	bool indexed;
 	uint32_t n_materials = 0;
