@@ -139,7 +139,8 @@ def test_several_devices_and_path_algo(tmp_path):
     assert np.array_equal(png.read_rgb8(a), png.read_rgb8(b))
 
 
-def test_textured_material(tmp_path):
+@pytest.mark.parametrize("tracer_name", ["hip indexed", "hip"])
+def test_textured_material(tracer_name, tmp_path):
     """A material library that names a PNG (`map_Kd`) and the `material texture <file> | drop` commands: the frame shows
     the texture as load_image3f would have handed it over (rows flipped, values to the power 2.2, libgi/scene.cpp:45-68),
     sampled like texture::sample (libgi/scene.h:24-32)."""
@@ -152,8 +153,8 @@ def test_textured_material(tmp_path):
         "mtllib quad.mtl\nv -2 -1 -4\nv 2 -1 -4\nv 2 1 -4\nv -2 1 -4\nv -2 -1.6 -4\nv 2 -1.6 -4\nvn 0 0 1\n"
         "vt 0 0\nvt 2.5 0\nvt 2.5 1.5\nvt 0 1.5\nusemtl wall\nf 1/1/1 2/2/1 3/3/1\nf 1/1/1 3/3/1 4/4/1\nusemtl plain\nf 5//1 6//1 2//1\n")
     w, h = 400, 300
-    body = ("at 0 0 0\nlook 0 0 -1\nup 0 1 0\nload %s\nraytracer hip indexed\ncommit\nalgo primary\nsppx 1\nhip jitter off\nresolution %d %d\n"
-            % (tmp_path / "quad.obj", w, h))
+    body = ("at 0 0 0\nlook 0 0 -1\nup 0 1 0\nload %s\nraytracer %s\ncommit\nalgo primary\nsppx 1\nhip jitter off\nresolution %d %d\n"
+            % (tmp_path / "quad.obj", tracer_name, w, h))
     out = [str(tmp_path / ("out%d.png" % k)) for k in range(3)]
     r = _run(body + "outfile %s\nrun\nmaterial select wall\nmaterial show\nmaterial texture %s\noutfile %s\nrun\nmaterial texture drop\noutfile %s\nrun\n"
              % (out[0], tmp_path / "other.png", out[1], out[2]), tmp_path)
