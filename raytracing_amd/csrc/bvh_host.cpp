@@ -447,6 +447,32 @@ bool validate_tree(HostTree &t, uint32_t n_triangles, std::string &err) {
 	return true;
 }
 
+namespace {
+// fn(begin, end) over [0, n) in contiguous parts, one per thread (as many as the builder uses); serial for small n
+// or when no thread can be had.
+template <class F>
+void parallel_ranges(uint32_t n, F fn) {
+	unsigned threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+	if (const char *e = getenv("RTGI_HIP_BUILD_THREADS")) threads = (unsigned)std::max(1, std::min(64, atoi(e)));
+	if (n < (1u << 16) || threads < 2) {
+		fn(0u, n);
+		return;
+	}
+	const uint32_t part = (n + threads - 1) / threads;
+	std::vector<std::thread> pool;
+	uint32_t begin = 0;
+	for (; begin + part < n; begin += part) {
+		try {
+			pool.emplace_back(fn, begin, begin + part);
+		} catch (const std::system_error &) {
+			break;  // the calling thread does the rest
+		}
+	}
+	fn(begin, n);
+	for (std::thread &th : pool) th.join();
+}
+}  // namespace
+
 void flatten_tree(const HostTree &t, const SceneView &scene, int layout, FlatTree &out) {
 	const uint32_t n = (uint32_t)t.nodes.size();
 	// Inner nodes are renumbered level by level (breadth first): the upper levels, which every ray visits,
@@ -493,40 +519,47 @@ void flatten_tree(const HostTree &t, const SceneView &scene, int layout, FlatTre
 	out.n_slots = (uint32_t)t.order.size();
 	out.depth = t.depth;
 	out.root_ref = ref_of(t.root);
+	// (the three record arrays are filled by several threads: every record depends on its own node or slot only)
 	out.nodes.assign((size_t)n_inner * 16, 0.0f);
-	for (uint32_t i = 0; i < n; ++i) {
-		const rtgi_node56 &nd = t.nodes[i];
-		if (nd.link_r < 0) continue;
-		float *g = out.nodes.data() + (size_t)inner_id[i] * 16;
-		int32_t rl = ref_of((uint32_t)nd.link_l), rr = ref_of((uint32_t)nd.link_r);
-		// child boxes interleaved (l, r) per coordinate: one packed instruction serves both children
-		const float *L = nd.box_l, *R = nd.box_r;  // min.xyz, max.xyz
-		const float packed[12] = {L[0], R[0], L[1], R[1], L[2], R[2], L[3], R[3], L[4], R[4], L[5], R[5]};
-		memcpy(g, packed, sizeof(packed));
-		memcpy(g + 12, &rl, 4);
-		memcpy(g + 13, &rr, 4);
-	}
-	out.tris.assign((size_t)out.n_slots * 12, 0.0f);
-	for (uint32_t s = 0; s < out.n_slots; ++s) {
-		const uint32_t *v = scene.tri(t.order[s]);
-		const float *A = scene.pos(v[0]), *B = scene.pos(v[1]), *C = scene.pos(v[2]);
-		float *g = out.tris.data() + (size_t)s * 12;
-		// hit ids: position in the permuted list (flat, bvh.h:96-100) or original id (indexed, :102-106)
-		uint32_t id = (layout == RTGI_LAYOUT_FLAT) ? s : t.order[s];
-		for (int k = 0; k < 3; ++k) {
-			g[k] = A[k];
-			g[4 + k] = A[k] - B[k];  // a, b, c of libgi/intersect.h:26-28
-			g[8 + k] = A[k] - C[k];  // d, e, f of :31-33
+	parallel_ranges(n, [&](uint32_t begin, uint32_t end) {
+		for (uint32_t i = begin; i < end; ++i) {
+			const rtgi_node56 &nd = t.nodes[i];
+			if (nd.link_r < 0) continue;
+			float *g = out.nodes.data() + (size_t)inner_id[i] * 16;
+			int32_t rl = ref_of((uint32_t)nd.link_l), rr = ref_of((uint32_t)nd.link_r);
+			// child boxes interleaved (l, r) per coordinate: one packed instruction serves both children
+			const float *L = nd.box_l, *R = nd.box_r;  // min.xyz, max.xyz
+			const float packed[12] = {L[0], R[0], L[1], R[1], L[2], R[2], L[3], R[3], L[4], R[4], L[5], R[5]};
+			memcpy(g, packed, sizeof(packed));
+			memcpy(g + 12, &rl, 4);
+			memcpy(g + 13, &rr, 4);
 		}
-		memcpy(g + 3, &id, 4);
-	}
+	});
+	out.tris.assign((size_t)out.n_slots * 12, 0.0f);
+	parallel_ranges(out.n_slots, [&](uint32_t begin, uint32_t end) {
+		for (uint32_t s = begin; s < end; ++s) {
+			const uint32_t *v = scene.tri(t.order[s]);
+			const float *A = scene.pos(v[0]), *B = scene.pos(v[1]), *C = scene.pos(v[2]);
+			float *g = out.tris.data() + (size_t)s * 12;
+			// hit ids: position in the permuted list (flat, bvh.h:96-100) or original id (indexed, :102-106)
+			uint32_t id = (layout == RTGI_LAYOUT_FLAT) ? s : t.order[s];
+			for (int k = 0; k < 3; ++k) {
+				g[k] = A[k];
+				g[4 + k] = A[k] - B[k];  // a, b, c of libgi/intersect.h:26-28
+				g[8 + k] = A[k] - C[k];  // d, e, f of :31-33
+			}
+			memcpy(g + 3, &id, 4);
+		}
+	});
 	// corner positions by reported id, for the stages that turn hits into new rays
 	const uint32_t n_ids = (layout == RTGI_LAYOUT_FLAT) ? out.n_slots : scene.n_triangles;
 	out.corners.assign((size_t)n_ids * 12, 0.0f);
-	for (uint32_t id = 0; id < n_ids; ++id) {
-		const uint32_t *v = scene.tri(layout == RTGI_LAYOUT_FLAT ? t.order[id] : id);
-		for (int c = 0; c < 3; ++c) memcpy(out.corners.data() + (size_t)id * 12 + 4 * c, scene.pos(v[c]), 12);
-	}
+	parallel_ranges(n_ids, [&](uint32_t begin, uint32_t end) {
+		for (uint32_t id = begin; id < end; ++id) {
+			const uint32_t *v = scene.tri(layout == RTGI_LAYOUT_FLAT ? t.order[id] : id);
+			for (int c = 0; c < 3; ++c) memcpy(out.corners.data() + (size_t)id * 12 + 4 * c, scene.pos(v[c]), 12);
+		}
+	});
 	for (uint32_t i = 0; i < n; ++i) {
 		const rtgi_node56 &nd = t.nodes[i];
 		if (nd.link_r >= 0) continue;
