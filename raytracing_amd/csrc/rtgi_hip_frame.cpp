@@ -247,17 +247,27 @@ template <class F>
 int for_each_part(rtgi_hip_renderer *r, F fn) {
 	const int n = (int)r->parts.size();
 	for (Part &p : r->parts) p.rc = RTGI_OK, p.error.clear();
+	// (nothing may leave a thread or this library as an exception: a part that runs out of memory fails like any other)
+	auto guarded = [r, &fn](int i) {
+		try {
+			fn(i);
+		} catch (const std::exception &e) {
+			fail(r->parts[(size_t)i], RTGI_ERR_NOMEM, std::string("exception: ") + e.what());
+		} catch (...) {
+			fail(r->parts[(size_t)i], RTGI_ERR_NOMEM, "exception");
+		}
+	};
 	if (n == 1)
-		fn(0);
+		guarded(0);
 	else {
 		std::vector<std::thread> threads;
 		try {
-			for (int i = 1; i < n; ++i) threads.emplace_back([&fn, i] { fn(i); });
+			for (int i = 1; i < n; ++i) threads.emplace_back([&guarded, i] { guarded(i); });
 		} catch (const std::exception &e) {
 			for (std::thread &t : threads) t.join();
 			return fail(r, RTGI_ERR_NOMEM, std::string("cannot start a host thread per GPU: ") + e.what());
 		}
-		fn(0);
+		guarded(0);
 		for (std::thread &t : threads) t.join();
 	}
 	for (int i = 0; i < n; ++i)
@@ -413,8 +423,21 @@ int rtgi_hip_renderer_set_textures(rtgi_hip_renderer *r, const void *vertex_tc, 
 	return RTGI_OK;
 }
 
+namespace {
+int render_frame(rtgi_hip_renderer *r, const rtgi_frame *frame, float *framebuffer, uint8_t *rgb8, rtgi_frame_stats *stats);
+}
 int rtgi_hip_renderer_render(rtgi_hip_renderer *r, const rtgi_frame *frame, float *framebuffer, uint8_t *rgb8, rtgi_frame_stats *stats) {
 	if (!r) return RTGI_ERR_INVALID;
+	try {
+		return render_frame(r, frame, framebuffer, rgb8, stats);
+	} catch (const std::exception &e) {
+		return fail(r, RTGI_ERR_NOMEM, std::string("render: ") + e.what());
+	} catch (...) {
+		return fail(r, RTGI_ERR_NOMEM, "render: exception");
+	}
+}
+namespace {
+int render_frame(rtgi_hip_renderer *r, const rtgi_frame *frame, float *framebuffer, uint8_t *rgb8, rtgi_frame_stats *stats) {
 	if (int rc = check_frame(r, frame)) return rc;
 	const rtgi_frame f = *frame;
 	const bool by_rank = r->world_size > 0;
@@ -493,6 +516,7 @@ int rtgi_hip_renderer_render(rtgi_hip_renderer *r, const rtgi_frame *frame, floa
 	}
 	return RTGI_OK;
 }
+}  // namespace
 
 const char *rtgi_hip_renderer_last_error(const rtgi_hip_renderer *r) { return r ? r->error.c_str() : g_create_error.c_str(); }
 
