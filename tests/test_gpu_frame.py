@@ -118,6 +118,29 @@ def test_tiles_over_several_handles_are_bit_identical(algo, bounces):
     assert np.array_equal(fb2.view(np.uint32), one.view(np.uint32))
 
 
+def test_deep_tree_mixed_batches_over_two_handles():
+    """A tree deeper than the LDS part of the stack (skewed scene, spatial-median splits) under `algo path`, whose
+    launches mix any_hit and closest_hit batches: two handles (tiles) render the frame of one, bit for bit."""
+    pos, tri, nrm = scenes.skewed(200000, seed=5)
+    s = dict(pos=pos, tri=tri, normals=nrm, material_id=np.zeros(len(tri), np.uint32), albedo=np.array([[0.6, 0.6, 0.6]], np.float32))
+    cam = dict(cam_pos=(0.0, 0.0, 2.0), cam_dir=(0.0, 0.0, -1.0), cam_up=(0.0, 1.0, 0.0))  # the dense middle of the scene fills the view
+    kw = dict(fovy=40.0, w=192, h=128, sppx=2, algo="path", bounces=2, light_pos=(0.5, 2.0, 1.5), light_col=(5.0, 5.0, 5.0), seed=8, **cam)
+    frames = []
+    for devices in ((0,), (0, 0)):
+        r = frame.HipRenderer(devices=devices, layout="indexed")
+        assert r.interprete("bvh", "sm")
+        r.build(s["pos"], s["normals"], s["tri"], s["material_id"], s["albedo"])
+        from raytracing_amd import tracer
+        import ctypes as C
+        depth = tracer.lib().rtgi_hip_depth(C.c_void_p(frame.lib().rtgi_hip_renderer_handle(r._r, 0)))
+        assert depth > 24, "the scene is meant to need the spill area (depth %d)" % depth
+        fb, _, st = r.render(sharding="tiles", **kw)
+        frames.append((fb, st))
+    assert np.array_equal(frames[0][0].view(np.uint32), frames[1][0].view(np.uint32))
+    assert frames[0][1]["rays"] == frames[1][1]["rays"] > 2.5 * 192 * 128 * 2  # most paths go on after the camera ray
+    assert (frames[0][0][:, 0:3].sum(1) > 0).mean() > 0.02
+
+
 def test_samples_over_several_handles():
     s = _scene()
     w, h, spp = 200, 120, 5
