@@ -440,7 +440,10 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 // sorted by a 24-bit key: direction octant (3 bits) | length class (5 bits, longest first) | the upper 16 bits of
 // the 18-bit Morton code of the origin inside the scene's bounds.
 constexpr int KEY_BITS = 24;
-constexpr int CLASS_BITS = 5;  // 3..8 measured: 32 classes are the optimum (-1.3 % against 8)
+#ifndef RTGI_CLASS_BITS
+#define RTGI_CLASS_BITS 5
+#endif
+constexpr int CLASS_BITS = RTGI_CLASS_BITS;  // 3..8 measured: 32 classes are the optimum (-1.3 % against 8)
 struct KeyArgs {
 	const float4 *rays;
 	uint32_t *keys;
