@@ -356,9 +356,9 @@ def main():
             "roofline": roofline(args.workload, total_bytes, n, kernel_ms, alg, lane_rate, miss_rate, rate_source),
         }
         # the drop-in form of the same call: rays and hits in host memory, PCIe both ways inside the call (never `value`)
-        if not args.no_host_buffers:
+        if not args.no_host_buffers and world == 1:
             out["host_buffer_path"] = host_buffer_rates(t, w["bounce"], d_hits)
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:  # the CPU leg is timed beside the one-GPU run only
             out["cpu_baseline"] = cpu_baseline(args, w, d_hits.cpu().numpy().view(np.dtype([("t", "<f4"), ("beta", "<f4"), ("gamma", "<f4"), ("ref", "<u4")])).reshape(-1))
         print(json.dumps(out), flush=True)
     if grouped:
