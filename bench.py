@@ -256,6 +256,21 @@ def _oracle_split(bvh):
     return kw
 
 
+def whole_job(elapsed, n, where, grouped):
+    """The job's time is its slowest rank's, its work the sum over the ranks (`where`: the device the process
+    group's backend exchanges tensors on)."""
+    import torch
+    import torch.distributed as dist
+    if not grouped:
+        return elapsed, float(n)
+    stats = torch.tensor([elapsed, float(n)], dtype=torch.float64, device=where)
+    mx = stats.clone()
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    sm = stats.clone()
+    dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+    return float(mx[0].item()), float(sm[1].item())
+
+
 def main():
     args = parse_args()
     import torch
@@ -315,15 +330,7 @@ def main():
     # the timed launches did the work: the last one's hit records are the counting launch's
     assert torch.equal(d_hits, alg["hits"]), "timed launch and counting launch disagree"
 
-    stats = torch.tensor([elapsed, float(n)], dtype=torch.float64, device="cuda:%d" % device if args.backend == "nccl" else "cpu")
-    if grouped:
-        mx = stats.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        sm = stats.clone()
-        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        elapsed, total_rays = float(mx[0].item()), float(sm[1].item())
-    else:
-        total_rays = float(n)
+    elapsed, total_rays = whole_job(elapsed, n, "cuda:%d" % device if args.backend == "nccl" else "cpu", grouped)
 
     if rank == 0:
         achieved = total_bytes / (kernel_ms * 1e-3) / 1e9

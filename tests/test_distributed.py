@@ -76,3 +76,23 @@ def test_running_mean_matches_reference_formula():
     assert torch.allclose(fb.color[..., 0:3], torch.full((3, 4, 3), 0.625)) and (fb.color[..., 3] == 2).all()
     img = fb.to_rgb8()
     assert img.shape == (3, 4, 3) and img[0, 0, 0] == int((0.625 ** (1 / 2.2)) * 255)
+
+
+def _bench_worker(rank, world, port, out_dir):
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    elapsed, rays = bench.whole_job(1.0 + rank, 100 * (rank + 1), "cpu", True)
+    np.save(os.path.join(out_dir, "job_%d.npy" % rank), np.array([elapsed, rays]))
+    dist.destroy_process_group()
+
+
+def test_bench_reports_slowest_rank_and_all_rays(tmp_path):
+    # bench.py: the job's time is the maximum over the ranks, its rays their sum, on every rank
+    world = 2
+    mp.spawn(_bench_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for rank in range(world):
+        assert np.load(tmp_path / ("job_%d.npy" % rank)).tolist() == [2.0, 300.0]
+    import bench
+    assert bench.whole_job(0.5, 7, "cpu", False) == (0.5, 7.0)
