@@ -73,39 +73,54 @@ public:
 
 	bool run(std::string &err) {
 		const uint32_t n = scene.n_triangles;
+		unsigned threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+		if (const char *e = getenv("RTGI_HIP_BUILD_THREADS")) threads = (unsigned)std::max(1, std::min(64, atoi(e)));
+		const int prep_parts = n >= FORK_MIN ? (int)std::min(threads, 16u) : 1;
 		boxes.resize(n);
 		owner.resize(n);
 		slots.resize(n);
-		for (uint32_t i = 0; i < n; ++i) {  // bvh2.cpp:35-43
-			const uint32_t *t = scene.tri(i);
-			boxes[i].add(load_pos(scene, t[0]));
-			boxes[i].add(load_pos(scene, t[1]));
-			boxes[i].add(load_pos(scene, t[2]));
-			owner[i] = i;
-			slots[i] = i;
-		}
+		on_threads(prep_parts, n, [this](uint32_t lo, uint32_t hi) {
+			for (uint32_t i = lo; i < hi; ++i) {  // bvh2.cpp:35-43
+				const uint32_t *t = scene.tri(i);
+				boxes[i].add(load_pos(scene, t[0]));
+				boxes[i].add(load_pos(scene, t[1]));
+				boxes[i].add(load_pos(scene, t[2]));
+				owner[i] = i;
+				slots[i] = i;
+			}
+		});
 		if (cfg.esc && !clip_large_triangles(err)) return false;
-		centre.resize(boxes.size());
-		for (size_t i = 0; i < boxes.size(); ++i)  // prim::center(), bvh.h:52
-			for (int k = 0; k < 3; ++k) centre[i][k] = (boxes[i].lo[k] + boxes[i].hi[k]) * 0.5f;
+		// One record per primitive box, kept in the order of the reference's `index` array: sorting and partitioning
+		// move the records themselves, so that a range of the recursion is a contiguous piece of memory.
+		prims.resize(boxes.size());
+		on_threads(prep_parts, (uint32_t)boxes.size(), [this](uint32_t lo, uint32_t hi) {
+			for (uint32_t i = lo; i < hi; ++i) {
+				Prim &p = prims[i];
+				p.box = boxes[slots[i]];
+				p.owner = owner[slots[i]];
+				for (int k = 0; k < 3; ++k) p.centre[k] = (p.box.lo[k] + p.box.hi[k]) * 0.5f;  // prim::center(), bvh.h:52
+			}
+		});
+		std::vector<Bounds>().swap(boxes);
+		std::vector<uint32_t>().swap(owner);
+		std::vector<uint32_t>().swap(slots);
 
 		// The two halves of a range are independent (each call sorts and partitions only its own part of
-		// `slots`), so the first levels of the recursion hand their left half to another thread. Every thread
-		// numbers its nodes from 0 in an arena of its own; joining appends the arenas in the reference's
+		// `prims`), so the first levels of the recursion hand their left half to another thread. Every thread
+		// numbers its nodes from 0 in an arena of its own; the arenas are put together at the end in the reference's
 		// pre-order (parent, left subtree, right subtree), which gives the node ids a single thread would.
-		unsigned threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-		if (const char *e = getenv("RTGI_HIP_BUILD_THREADS")) threads = (unsigned)std::max(1, std::min(64, atoi(e)));
 		int fork_levels = 0;
 		while ((1u << fork_levels) < threads) ++fork_levels;
 		Arena arena;
-		arena.nodes.reserve(2 * boxes.size());
-		out.root = split_range(0, (uint32_t)boxes.size(), 0, arena, fork_levels);
-		out.nodes = std::move(arena.nodes);
-		out.depth = arena.deepest;
+		if (fork_levels == 0) arena.nodes.reserve(2 * prims.size());
+		out.root = split_range(0, (uint32_t)prims.size(), 0, arena, fork_levels);
+		assemble(arena, out.nodes, out.depth);
 
 		// commit_shuffled_triangles, bvh2.cpp:172-190: slot -> original triangle id
-		out.order.resize(slots.size());
-		for (size_t s = 0; s < slots.size(); ++s) out.order[s] = owner[slots[s]];
+		out.order.resize(prims.size());
+		on_threads(prep_parts, (uint32_t)prims.size(), [this](uint32_t lo, uint32_t hi) {
+			for (uint32_t s = lo; s < hi; ++s) out.order[s] = prims[s].owner;
+		});
 		return true;
 	}
 
@@ -113,14 +128,25 @@ private:
 	const BuildConfig &cfg;
 	const SceneView &scene;
 	HostTree &out;
+	// while the primitive boxes are made (early split clipping adds some):
 	std::vector<Bounds> boxes;    // one per primitive box (more than triangles after clipping)
 	std::vector<uint32_t> owner;  // primitive box -> triangle
-	std::vector<F3> centre;
-	std::vector<uint32_t> slots;  // the 'index' array the reference sorts
+	std::vector<uint32_t> slots;  // the reference's 'index' array before the first split
+	// while the tree is built: position i holds what the reference reaches through index[i]
+	struct Prim {
+		Bounds box;
+		F3 centre;
+		uint32_t owner;
+	};
+	std::vector<Prim> prims;
 
+	// Nodes in pre-order, numbered from 0. A call of the recursion that handed its halves to other threads holds its
+	// one node here and the two subtrees as arenas of their own, which follow that node in the numbering.
 	struct Arena {
 		std::vector<rtgi_node56> nodes;
+		std::vector<Arena> then;  // subtrees numbered after `nodes`, in this order
 		uint32_t deepest = 0;
+		uint32_t count = 0;       // nodes.size() + the counts of `then`, kept by attach()
 	};
 	static constexpr uint32_t FORK_MIN = 1u << 14;  // smaller ranges are not worth a thread
 
@@ -139,36 +165,242 @@ private:
 		if (depth > a.deepest) a.deepest = depth;
 		return id;
 	}
-	// Appends a subtree built in its own arena (root = its node 0); returns the root's id in `a`.
-	static uint32_t append(Arena &a, const Arena &sub) {
-		const int32_t offset = (int32_t)a.nodes.size();
-		for (rtgi_node56 n : sub.nodes) {
-			if (n.link_r >= 0) n.link_l += offset, n.link_r += offset;  // inner node: links are node ids
-			a.nodes.push_back(n);
-		}
+	static uint32_t size_of(const Arena &a) { return a.then.empty() ? (uint32_t)a.nodes.size() : a.count; }
+	// Numbers a subtree built in its own arena (root = its node 0) after everything `a` holds so far; returns the
+	// root's id in `a`. Nothing is copied before assemble().
+	static uint32_t attach(Arena &a, Arena &&sub) {
+		if (a.then.empty()) a.count = (uint32_t)a.nodes.size();
+		const uint32_t offset = a.count;
+		a.count += size_of(sub);
 		if (sub.deepest > a.deepest) a.deepest = sub.deepest;
-		return (uint32_t)offset;
+		a.then.push_back(std::move(sub));
+		return offset;
+	}
+	// All arenas into one array, each copied once (by a thread of its own) to where its numbering starts; the links of
+	// inner nodes are ids inside their arena and move with it.
+	static void assemble(Arena &root, std::vector<rtgi_node56> &nodes, uint32_t &deepest) {
+		deepest = root.deepest;
+		if (root.then.empty()) {
+			nodes = std::move(root.nodes);
+			return;
+		}
+		struct Piece {
+			const Arena *arena;
+			uint32_t at;
+		};
+		std::vector<Piece> pieces;
+		auto collect = [&pieces](auto &&self, const Arena &a, uint32_t at) -> void {
+			pieces.push_back({&a, at});
+			uint32_t next = at + (uint32_t)a.nodes.size();
+			for (const Arena &sub : a.then) {
+				self(self, sub, next);
+				next += size_of(sub);
+			}
+		};
+		collect(collect, root, 0);
+		nodes.resize(size_of(root));
+		rtgi_node56 *out = nodes.data();
+		auto place = [out](const Piece &p) {
+			for (size_t i = 0; i < p.arena->nodes.size(); ++i) {
+				rtgi_node56 n = p.arena->nodes[i];
+				if (n.link_r >= 0) n.link_l += (int32_t)p.at, n.link_r += (int32_t)p.at;  // inner node: links are node ids
+				out[p.at + i] = n;
+			}
+		};
+		std::vector<std::thread> threads;
+		for (const Piece &p : pieces) {
+			bool started = false;
+			if (p.arena->nodes.size() >= FORK_MIN && threads.size() < 64) try {
+					threads.emplace_back([&place, p] { place(p); });
+					started = true;
+				} catch (const std::system_error &) {
+				}
+			if (!started) place(p);
+		}
+		for (std::thread &t : threads) t.join();
 	}
 	Bounds range_bounds(uint32_t start, uint32_t end) const {
 		Bounds b;
-		for (uint32_t i = start; i < end; ++i) b.add(boxes[slots[i]]);
+		for (uint32_t i = start; i < end; ++i) b.add(prims[i].box);
 		return b;
 	}
-	void sort_by_centre(uint32_t start, uint32_t end, int axis) {
-		std::sort(slots.data() + start, slots.data() + end,
-		          [this, axis](uint32_t a, uint32_t b) { return centre[a][axis] < centre[b][axis]; });
+	// std::sort of the range by the centre along `axis` (bvh2.cpp:214-222). The order std::sort leaves equal centres
+	// in is part of the reference's tree (a million random centres hold tens of thousands of equal pairs), so the
+	// result has to be that of libstdc++'s std::sort on this range with this comparison. std::sort's moves depend on
+	// the outcomes of its comparisons only, so sorting small (centre, position) records instead of the reference's
+	// indices leaves everything in the same places, ties included; the primitive records are then put into that
+	// order in one pass. A large range near the root, where few threads have work yet, goes through sort_as_std,
+	// which forks where std::sort recurses.
+	struct Keyed {
+		float key;
+		uint32_t slot;
+	};
+	static bool by_key(const Keyed &a, const Keyed &b) { return a.key < b.key; }
+	static constexpr uint32_t PARALLEL_SORT_MIN = 1u << 15;
+
+	void sort_by_centre(uint32_t start, uint32_t end, int axis, int spare_levels = 0) {
+		const uint32_t n = end - start;
+		if (n < 32) {
+			std::sort(prims.data() + start, prims.data() + end, [axis](const Prim &a, const Prim &b) { return a.centre[axis] < b.centre[axis]; });
+			return;
+		}
+		static thread_local std::vector<Keyed> keyed;
+		static thread_local std::vector<Prim> moved;
+		keyed.resize(n);
+		moved.resize(n);
+		for (uint32_t i = 0; i < n; ++i) keyed[i] = Keyed{prims[start + i].centre[axis], i};
+		if (spare_levels > 0 && n >= PARALLEL_SORT_MIN) {
+			sort_as_std(keyed.data(), keyed.data() + n, spare_levels);
+			const Keyed *k = keyed.data();
+			Prim *to = moved.data();
+			const Prim *from = prims.data() + start;
+			on_threads(1 << std::min(spare_levels, 4), n, [=](uint32_t lo, uint32_t hi) {
+				for (uint32_t i = lo; i < hi; ++i) to[i] = from[k[i].slot];
+			});
+		} else {
+			std::sort(keyed.begin(), keyed.end(), by_key);
+			for (uint32_t i = 0; i < n; ++i) moved[i] = prims[start + keyed[i].slot];
+		}
+		std::memcpy(prims.data() + start, moved.data(), (size_t)n * sizeof(Prim));
 	}
+
+	// fn(lo, hi) over [0, n) cut into `parts` pieces, one thread each (the last piece on this thread; a piece whose
+	// thread cannot be started runs here too).
+	template <class F>
+	static void on_threads(int parts, uint32_t n, F fn) {
+		std::vector<std::thread> threads;
+		for (int i = 0; i < parts; ++i) {
+			const uint32_t lo = (uint32_t)((uint64_t)n * (uint32_t)i / (uint32_t)parts), hi = (uint32_t)((uint64_t)n * (uint32_t)(i + 1) / (uint32_t)parts);
+			bool started = false;
+			if (i + 1 < parts) try {
+					threads.emplace_back([=] { fn(lo, hi); });
+					started = true;
+				} catch (const std::system_error &) {
+				}
+			if (!started) fn(lo, hi);
+		}
+		for (std::thread &t : threads) t.join();
+	}
+
+	// libstdc++'s std::sort (introsort: median-of-three quicksort down to pieces of 16, heapsort below a depth limit,
+	// one insertion sort over everything at the end), restated so that the two sides of a partition can be sorted by
+	// different threads. Each step compares and moves what std::sort would, so equal keys end up where std::sort
+	// leaves them; tests compare the resulting trees with those built through std::sort itself.
+	static constexpr long SORT_PIECE = 16;
+	static void insert_unguarded(Keyed *last) {  // a smaller-or-equal element is known to lie to the left
+		const Keyed v = *last;
+		Keyed *next = last - 1;
+		while (by_key(v, *next)) {
+			*last = *next;
+			last = next;
+			--next;
+		}
+		*last = v;
+	}
+	static void insertion_sort(Keyed *first, Keyed *last) {
+		if (first == last) return;
+		for (Keyed *i = first + 1; i != last; ++i) {
+			if (by_key(*i, *first)) {
+				const Keyed v = *i;
+				std::move_backward(first, i, i + 1);
+				*first = v;
+			} else
+				insert_unguarded(i);
+		}
+	}
+	static Keyed *partition_around_median(Keyed *first, Keyed *last) {
+		Keyed *a = first + 1, *b = first + (last - first) / 2, *c = last - 1;
+		// the median of a, b, c goes to `first`
+		if (by_key(*a, *b)) {
+			if (by_key(*b, *c)) std::iter_swap(first, b);
+			else if (by_key(*a, *c)) std::iter_swap(first, c);
+			else std::iter_swap(first, a);
+		} else if (by_key(*a, *c)) std::iter_swap(first, a);
+		else if (by_key(*b, *c)) std::iter_swap(first, c);
+		else std::iter_swap(first, b);
+		Keyed *lo = first + 1, *hi = last;
+		for (;;) {
+			while (by_key(*lo, *first)) ++lo;
+			--hi;
+			while (by_key(*first, *hi)) --hi;
+			if (!(lo < hi)) return lo;
+			std::iter_swap(lo, hi);
+			++lo;
+		}
+	}
+	// Insertion sort of [first, last) that never looks left of `first`. For a part of the array whose left neighbours
+	// are all smaller or equal it moves exactly what the unguarded loop at the end of std::sort moves: that loop
+	// stops at the part's first element or before, since it passes strictly greater elements only.
+	static void insertion_sort_from(Keyed *first, Keyed *last) {
+		for (Keyed *i = first; i != last; ++i) {
+			const Keyed v = *i;
+			Keyed *j = i;
+			while (j != first && by_key(v, *(j - 1))) {
+				*j = *(j - 1);
+				--j;
+			}
+			*j = v;
+		}
+	}
+	// Returns where the part still waiting for its insertion pass ends: parts handed to other threads lie to the
+	// right of it and are finished, insertion pass included, when this returns.
+	static Keyed *quicksort_pieces(Keyed *first, Keyed *last, long depth_limit, int spare_levels) {
+		std::vector<std::thread> forked;
+		Keyed *mine_end = last;
+		while (last - first > SORT_PIECE) {
+			if (depth_limit == 0) {
+				std::partial_sort(first, last, last, by_key);  // heapsort of the piece
+				break;
+			}
+			--depth_limit;
+			Keyed *cut = partition_around_median(first, last);
+			// std::sort recurses into [cut, last) and goes on with [first, cut). Everything in [cut, last) is greater or
+			// equal to everything left of it, so another thread can take it to the end (as long as the parts given
+			// away form one stretch at the right end).
+			bool started = false;
+			if (spare_levels > 0 && last == mine_end && last - cut >= (long)(PARALLEL_SORT_MIN / 8)) {
+				--spare_levels;
+				const int levels = spare_levels;
+				try {
+					forked.emplace_back([=] {
+						Keyed *todo = quicksort_pieces(cut, last, depth_limit, levels);
+						insertion_sort_from(cut, todo);
+					});
+					started = true;
+					mine_end = cut;
+				} catch (const std::system_error &) {
+				}
+			}
+			if (!started) (void)quicksort_pieces(cut, last, depth_limit, 0);
+			last = cut;
+		}
+		for (std::thread &t : forked) t.join();
+		return mine_end;
+	}
+	static void sort_as_std(Keyed *first, Keyed *last, int spare_levels) {
+		if (first == last) return;
+		long lg = 0;
+		for (unsigned long m = (unsigned long)(last - first); m > 1; m >>= 1) ++lg;
+		Keyed *todo = quicksort_pieces(first, last, 2 * lg, std::min(spare_levels, 4));
+		// std::sort's last step over what no other thread has finished
+		if (todo - first > SORT_PIECE) {
+			insertion_sort(first, first + SORT_PIECE);
+			for (Keyed *i = first + SORT_PIECE; i != todo; ++i) insert_unguarded(i);
+		} else
+			insertion_sort(first, todo);
+	}
+
 	// Two-pointer partition of bvh2.cpp:265-277 / :338-353. The slot on which the pointers meet is
 	// left unexamined on the right-hand side, exactly as there.
 	uint32_t partition_at(uint32_t start, uint32_t end, int axis, float plane) {
 		uint32_t mid = start, l = start, r = end - 1;
 		while (l < r) {
-			while (centre[slots[l]][axis] <= plane && l < r) {
+			while (prims[l].centre[axis] <= plane && l < r) {
 				++l;
 				++mid;
 			}
-			while (centre[slots[r]][axis] > plane && l < r) --r;
-			if (centre[slots[l]][axis] > centre[slots[r]][axis] && l < r) std::swap(slots[l], slots[r]);
+			while (prims[r].centre[axis] > plane && l < r) --r;
+			if (prims[l].centre[axis] > prims[r].centre[axis] && l < r) std::swap(prims[l], prims[r]);
 		}
 		return mid;
 	}
@@ -183,13 +415,13 @@ private:
 		bool have_child_boxes = false;
 
 		if (cfg.split == RTGI_SPLIT_OM) {  // bvh2.cpp:192-235
-			sort_by_centre(start, end, axis);
+			sort_by_centre(start, end, axis, fork_levels);
 			mid = start + (end - start) / 2;
 		} else if (cfg.split == RTGI_SPLIT_SM) {  // bvh2.cpp:237-298
 			float plane = all.lo[axis] + (all.hi[axis] - all.lo[axis]) * 0.5f;
 			mid = partition_at(start, end, axis, plane);
 			if (mid == start || mid == end - 1) {
-				sort_by_centre(start, end, axis);
+				sort_by_centre(start, end, axis, fork_levels);
 				mid = start + (end - start) / 2;
 			}
 		} else {  // bvh2.cpp:300-413
@@ -203,7 +435,7 @@ private:
 				uint32_t m = partition_at(start, end, axis, plane);
 				if (m == start || m == end - 1) {
 					if (!median_fallback_left) continue;
-					sort_by_centre(start, end, axis);
+					sort_by_centre(start, end, axis, fork_levels);
 					m = start + (end - start) / 2;
 					median_fallback_left = false;
 				}
@@ -224,7 +456,7 @@ private:
 				// axis-parallel line), so every cost is NaN or inf and never below the best so far. The reference
 				// would recurse into an empty range here and stop at its assert (bvh2.cpp:302); split at the
 				// object median instead, which always makes progress.
-				sort_by_centre(start, end, axis);
+				sort_by_centre(start, end, axis, fork_levels);
 				mid = start + (end - start) / 2;
 				have_child_boxes = false;
 			}
@@ -261,8 +493,8 @@ private:
 			else
 				left_half();
 			if (failure) std::rethrow_exception(failure);
-			l = append(arena, sub_l);
-			r = append(arena, sub_r);
+			l = attach(arena, std::move(sub_l));
+			r = attach(arena, std::move(sub_r));
 		} else {
 			l = split_range(start, mid, depth + 1, arena, 0);
 			r = split_range(mid, end, depth + 1, arena, 0);

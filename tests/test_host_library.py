@@ -169,6 +169,28 @@ def test_threaded_build_equals_single_threaded_build(cmds, monkeypatch):
     # ranges of 2^14 primitives and more fork a thread per half on the first levels; node ids, boxes and the
     # triangle order must not depend on the number of threads, and must still be the oracle's
     pos, tri, _ = scenes.soup(100000, seed=4, size=0.3)
+    _threads_do_not_matter(pos, tri, cmds, monkeypatch)
+
+
+@pytest.mark.parametrize("cmds", [(), ("sm",)])
+def test_threaded_build_with_many_equal_centres(cmds, monkeypatch):
+    # Vertices on a coarse grid: thousands of primitives share a centre coordinate, and where std::sort leaves equal
+    # elements is part of the tree. Large ranges are sorted on several threads by the builder's own statement of
+    # std::sort; its trees must be those of one thread (which calls std::sort) and of the oracle.
+    pos, tri, _ = scenes.soup(70000, seed=9, size=0.5)
+    pos = (np.round(pos * 4) / 4).astype(np.float32)
+    _threads_do_not_matter(pos, tri, cmds, monkeypatch)
+    if not cmds:  # every centre equal, and centres already in rising / falling order
+        same = np.tile(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32), (40000, 1))
+        tri = np.arange(len(same), dtype=np.uint32).reshape(-1, 3)
+        _threads_do_not_matter(same, tri, cmds, monkeypatch)
+        for sign in (1.0, -1.0):
+            ramp = same.copy()
+            ramp[:, 0] += sign * np.repeat(np.arange(40000, dtype=np.float32), 3)
+            _threads_do_not_matter(ramp, tri, cmds, monkeypatch)
+
+
+def _threads_do_not_matter(pos, tri, cmds, monkeypatch):
     trees = []
     for threads in ("1", "2", "7"):
         monkeypatch.setenv("RTGI_HIP_BUILD_THREADS", threads)
