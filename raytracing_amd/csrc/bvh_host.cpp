@@ -792,13 +792,15 @@ void flatten_tree(const HostTree &t, const SceneView &scene, int layout, FlatTre
 			for (int c = 0; c < 3; ++c) memcpy(out.corners.data() + (size_t)id * 12 + 4 * c, scene.pos(v[c]), 12);
 		}
 	});
-	for (uint32_t i = 0; i < n; ++i) {
-		const rtgi_node56 &nd = t.nodes[i];
-		if (nd.link_r >= 0) continue;
-		uint32_t last = (uint32_t)(-nd.link_l) + (uint32_t)(-nd.link_r) - 1;
-		uint32_t one = 1;
-		memcpy(out.tris.data() + (size_t)last * 12 + 7, &one, 4);
-	}
+	parallel_ranges(n, [&](uint32_t begin, uint32_t end) {  // (leaves cover disjoint slots)
+		for (uint32_t i = begin; i < end; ++i) {
+			const rtgi_node56 &nd = t.nodes[i];
+			if (nd.link_r >= 0) continue;
+			uint32_t last = (uint32_t)(-nd.link_l) + (uint32_t)(-nd.link_r) - 1;
+			uint32_t one = 1;
+			memcpy(out.tris.data() + (size_t)last * 12 + 7, &one, 4);
+		}
+	});
 }
 
 // print_node_stats, bvh2.cpp:599-630 (same figures, including its min/max update order and its
