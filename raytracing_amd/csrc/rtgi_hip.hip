@@ -631,7 +631,7 @@ int launch_batches(rtgi_hip_tracer *h, const BatchView *given, uint32_t n_given,
 		if (v[7])
 			fprintf(stderr, "diag(prev launch): inner iters fed %llu (%.1f%% lanes) | dry %llu (%.1f%% lanes) | refills %llu outer %llu | wall %.3f ms, supply dry at %.3f..%.3f ms, mean wave life %.3f ms\n",
 			        v[0], v[0] ? 100.0 * v[1] / (64.0 * v[0]) : 0.0, v[2], v[2] ? 100.0 * v[3] / (64.0 * v[2]) : 0.0, v[6], v[7],
-			        (v[9] - v[8]) * 1e-5, (v[10] - v[8]) * 1e-5, (v[11] - v[8]) * 1e-5, v[12] * 1e-5 / (double)(h->grid_blocks * 4));
+			        (v[9] - v[8]) * 1e-5, (v[10] - v[8]) * 1e-5, (v[11] - v[8]) * 1e-5, v[12] * 1e-5 / (double)(h->grid_blocks * (BLOCK / 64)));
 	}
 #endif
 	a.refill_min = h->refill_min;
