@@ -169,6 +169,7 @@ public:
 	// the permuted one, exactly like commit_shuffled_triangles (bvh2.cpp:172-180) does.
 	template <class Scene>
 	void build(Scene *s) {
+		require_scene(s);
 		check(rtgi_hip_build(h, &s->vertices[0].pos, sizeof(s->vertices[0]), (uint32_t)s->vertices.size(), &s->triangles[0].a,
 		                     sizeof(s->triangles[0]), (uint32_t)s->triangles.size()));
 		permute(s);
@@ -179,6 +180,7 @@ public:
 	// rtgi_hip_build and the permutation of scene->triangles, i.e. use build(s, albedo, n) below.
 	template <class Scene>
 	void build(Scene *s, const float *albedo_rgb, uint32_t n_materials) {
+		require_scene(s);
 		check(rtgi_hip_build(h, &s->vertices[0].pos, sizeof(s->vertices[0]), (uint32_t)s->vertices.size(), &s->triangles[0].a,
 		                     sizeof(s->triangles[0]), (uint32_t)s->triangles.size()));
 		check(rtgi_hip_set_shading(h, &s->vertices[0].norm, sizeof(s->vertices[0]), (uint32_t)s->vertices.size(), &s->triangles[0].a,
@@ -217,6 +219,10 @@ public:
 	rtgi_hip_tracer *handle() { return h; }
 
 private:
+	template <class Scene>
+	static void require_scene(Scene *s) {  // (the arrays' first elements are addressed below)
+		if (!s || s->vertices.empty() || s->triangles.empty()) throw std::runtime_error("rtgi_hip: there is no scene data to work with");
+	}
 	template <class Scene>
 	void permute(Scene *s) {
 		if (indexed) return;
@@ -435,6 +441,7 @@ public:
 	// ray_tracer::build. Materials are read by materials_of(scene) (inside the renderer: scene->materials; the
 	// stand-alone mirror scene has none, so set_materials() is called by hand); lambertian grey until then.
 	void build(rtgi_hip::scene *s) override {
+		if (!s || s->vertices.empty() || s->triangles.empty()) throw std::runtime_error("rtgi_hip: there is no scene data to work with");
 		this->scene = s;
 		std::vector<hip_material> m = materials_of(s);
 		std::vector<float> albedo;
