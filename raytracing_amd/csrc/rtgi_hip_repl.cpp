@@ -127,7 +127,7 @@ bool read_png(const std::string &path, unsigned &w, unsigned &h, std::vector<flo
 		at += 12 + (size_t)len;
 	}
 	const unsigned channels = type == 0 ? 1 : type == 2 ? 3 : type == 3 ? 1 : type == 4 ? 2 : type == 6 ? 4 : 0;
-	if (!w || !h || w > 32768 || h > 32768 || !channels || interlace || (depth != 8 && depth != 16) || (type == 3 && depth != 8))
+	if (!w || !h || w > 32768 || h > 32768 || (uint64_t)w * h > (1ull << 26) || !channels || interlace || (depth != 8 && depth != 16) || (type == 3 && depth != 8))
 		return err = path + ": unsupported kind of PNG (8 or 16 bits per channel, not interlaced)", false;
 	const size_t bpp = channels * depth / 8, stride = (size_t)w * bpp;
 	std::vector<unsigned char> raw((stride + 1) * h);
