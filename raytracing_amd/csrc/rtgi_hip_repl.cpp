@@ -880,7 +880,16 @@ void Repl::loop(std::istream &infile, bool prompt) {
 
 }  // namespace
 
+int run(int argc, char **argv);
 int main(int argc, char **argv) {
+	try {
+		return run(argc, argv);
+	} catch (const std::exception &e) {  // (out of memory on a huge scene, a stream failure)
+		std::cerr << "rtgi_hip_repl: " << e.what() << std::endl;
+		return 3;
+	}
+}
+int run(int argc, char **argv) {
 	Repl repl;
 	for (int i = 1; i < argc; ++i) {
 		const std::string a = argv[i];
