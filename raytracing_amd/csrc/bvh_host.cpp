@@ -115,6 +115,8 @@ public:
 		if (fork_levels == 0) arena.nodes.reserve(2 * prims.size());
 		out.root = split_range(0, (uint32_t)prims.size(), 0, arena, fork_levels);
 		assemble(arena, out.nodes, out.depth);
+		std::vector<Keyed>().swap(keyed_buffer());
+		std::vector<Prim>().swap(moved_buffer());
 
 		// commit_shuffled_triangles, bvh2.cpp:172-190: slot -> original triangle id
 		out.order.resize(prims.size());
@@ -208,6 +210,7 @@ private:
 			}
 		};
 		std::vector<std::thread> threads;
+		threads.reserve(64);
 		for (const Piece &p : pieces) {
 			bool started = false;
 			if (p.arena->nodes.size() >= FORK_MIN && threads.size() < 64) try {
@@ -238,14 +241,24 @@ private:
 	static bool by_key(const Keyed &a, const Keyed &b) { return a.key < b.key; }
 	static constexpr uint32_t PARALLEL_SORT_MIN = 1u << 15;
 
+	// working memory of sort_by_centre, one set per thread (a thread's set goes with the thread; run() gives back
+	// the calling thread's)
+	static std::vector<Keyed> &keyed_buffer() {
+		static thread_local std::vector<Keyed> v;
+		return v;
+	}
+	static std::vector<Prim> &moved_buffer() {
+		static thread_local std::vector<Prim> v;
+		return v;
+	}
 	void sort_by_centre(uint32_t start, uint32_t end, int axis, int spare_levels = 0) {
 		const uint32_t n = end - start;
 		if (n < 32) {
 			std::sort(prims.data() + start, prims.data() + end, [axis](const Prim &a, const Prim &b) { return a.centre[axis] < b.centre[axis]; });
 			return;
 		}
-		static thread_local std::vector<Keyed> keyed;
-		static thread_local std::vector<Prim> moved;
+		std::vector<Keyed> &keyed = keyed_buffer();
+		std::vector<Prim> &moved = moved_buffer();
 		keyed.resize(n);
 		moved.resize(n);
 		for (uint32_t i = 0; i < n; ++i) keyed[i] = Keyed{prims[start + i].centre[axis], i};
@@ -269,6 +282,7 @@ private:
 	template <class F>
 	static void on_threads(int parts, uint32_t n, F fn) {
 		std::vector<std::thread> threads;
+		threads.reserve((size_t)std::max(parts, 1));  // (no reallocation, and so no exception, while threads are running)
 		for (int i = 0; i < parts; ++i) {
 			const uint32_t lo = (uint32_t)((uint64_t)n * (uint32_t)i / (uint32_t)parts), hi = (uint32_t)((uint64_t)n * (uint32_t)(i + 1) / (uint32_t)parts);
 			bool started = false;
@@ -346,6 +360,11 @@ private:
 	// right of it and are finished, insertion pass included, when this returns.
 	static Keyed *quicksort_pieces(Keyed *first, Keyed *last, long depth_limit, int spare_levels) {
 		std::vector<std::thread> forked;
+		try {
+			forked.reserve(8);  // (at most four forks per call; no reallocation while threads are running)
+		} catch (const std::bad_alloc &) {
+			spare_levels = 0;  // nothing below can throw then: this may be running on a thread of its own
+		}
 		Keyed *mine_end = last;
 		while (last - first > SORT_PIECE) {
 			if (depth_limit == 0) {
