@@ -299,7 +299,10 @@ void read_tunables(rtgi_hip_tracer *h) {
 
 int upload(rtgi_hip_tracer *h, const rtgi::SceneView &scene) {
 	rtgi::FlatTree flat;
+	const std::chrono::steady_clock::time_point flatten_begin = std::chrono::steady_clock::now();
 	rtgi::flatten_tree(h->tree, scene, h->cfg.layout, flat);
+	if (getenv("RTGI_HIP_BUILD_TIMES"))
+		fprintf(stderr, "rtgi_hip_build: flatten %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - flatten_begin).count());
 	if (h->device < 0) return RTGI_OK;
 	DeviceScope device_scope(h->device);
 	HIP_TRY(h, device_scope.status);
@@ -1067,10 +1070,18 @@ int rtgi_hip_build(rtgi_hip_tracer *h, const void *vertices, size_t vertex_strid
 	std::string err;
 	rtgi::HostTree tree;
 	try {
+		using clock = std::chrono::steady_clock;
+		auto ms = [](clock::time_point a, clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+		const clock::time_point t0 = clock::now();
 		if (!rtgi::build_tree(h->cfg, scene, tree, err)) return fail(h, RTGI_ERR_INVALID, err);
 		h->tree = std::move(tree);
+		const clock::time_point t1 = clock::now();
 		int rc_upload = upload(h, scene);
-		return rc_upload ? rc_upload : probe_scene(h);
+		const clock::time_point t2 = clock::now();
+		const int rc = rc_upload ? rc_upload : probe_scene(h);
+		if (getenv("RTGI_HIP_BUILD_TIMES"))  // where a commit's time goes
+			fprintf(stderr, "rtgi_hip_build: tree %.1f ms, flatten and upload %.1f ms, probe rays %.1f ms\n", ms(t0, t1), ms(t1, t2), ms(t2, clock::now()));
+		return rc;
 	} catch (const std::bad_alloc &) {
 		return fail(h, RTGI_ERR_NOMEM, "out of host memory while building the BVH");
 	} catch (const std::exception &e) {
