@@ -92,6 +92,17 @@ int rtgi_hip_interprete(rtgi_hip_tracer *h, const char *command, const char *arg
 int rtgi_hip_build(rtgi_hip_tracer *h, const void *vertices, size_t vertex_stride, uint32_t n_vertices,
                    const void *triangles, size_t tri_stride, uint32_t n_triangles);
 
+/* build() for a tracer that spans several GPUs (`raytracer hip devices N`: one handle per GPU, every GPU with the
+ * whole BVH; no counterpart in the reference, which has one tracer in one process): the tree is built ONCE on the
+ * host from the settings of handles[0] (all handles must have been created and configured alike), flattened once,
+ * and uploaded to every handle's GPU, the uploads running side by side. Each handle afterwards is in the state
+ * rtgi_hip_build leaves it in. Errors are reported on handles[0]. */
+int rtgi_hip_build_shared(rtgi_hip_tracer *const *handles, uint32_t n_handles, const void *vertices, size_t vertex_stride,
+                          uint32_t n_vertices, const void *triangles, size_t tri_stride, uint32_t n_triangles);
+
+/* The GPU a handle is bound to (the `device` given to rtgi_hip_create; -1 for a host-only handle or NULL). */
+int rtgi_hip_device_of(const rtgi_hip_tracer *h);
+
 /* Takes a tree built elsewhere (e.g. by the reference's own builder) verbatim: `nodes`/`root` as in
  * binary_bvh_tracer::nodes/root (bvh.h:59-68); `index` = the leaf-order triangle list, i.e.
  * binary_bvh_tracer::index for the indexed layout, NULL (identity over the already permuted

@@ -71,7 +71,10 @@ rtgi_hip_renderer *rtgi_hip_renderer_create(const int *devices, int n, int layou
  * that one process gets from rtgi_hip_renderer_unique_id and hands to the others by whatever means the launcher has
  * (a broadcast, a file); create_rank returns when all `world` processes have called it (ncclCommInitRank). render()
  * is then a collective call: every rank calls it with the same frame, renders its tiles (or samples), and receives
- * the whole frame through one ncclAllReduce; stats->rays counts this rank's rays only. */
+ * the whole frame through one ncclAllReduce; stats->rays counts this rank's rays only. A rank whose part fails still
+ * takes part in a one-word status exchange first, so that all ranks return an error together instead of the others
+ * waiting in the all-reduce; if the exchange itself fails the communicator is given up (ncclCommAbort) and the
+ * renderer must be created again. */
 int rtgi_hip_renderer_unique_id(void *out, size_t bytes);
 rtgi_hip_renderer *rtgi_hip_renderer_create_rank(int device, int layout, int esc, int rank, int world, const void *unique_id);
 void rtgi_hip_renderer_destroy(rtgi_hip_renderer *r);
@@ -84,7 +87,8 @@ int rtgi_hip_renderer_interprete(rtgi_hip_renderer *r, const char *command, cons
 
 /* ray_tracer::build + the shading data, arguments as rtgi_hip_build and rtgi_hip_set_shading: vertices = first
  * struct vertex (position at offset 0, normal at offset 12; sizeof(vertex) = 32, libgi/rt.h:29-33), triangles =
- * first struct triangle (a, b, c, material_id). Every GPU builds the same tree, in parallel. */
+ * first struct triangle (a, b, c, material_id). The tree is built once on the host and uploaded to every GPU
+ * (rtgi_hip_build_shared). */
 int rtgi_hip_renderer_build(rtgi_hip_renderer *r, const void *vertices, size_t vertex_stride, uint32_t n_vertices,
                             const void *triangles, size_t tri_stride, uint32_t n_triangles, const float *albedo_rgb,
                             uint32_t n_materials);
@@ -103,6 +107,11 @@ int rtgi_hip_renderer_set_textures(rtgi_hip_renderer *r, const void *vertex_tc, 
  * framebuffer::png (top row first), or NULL; stats: or NULL. */
 int rtgi_hip_renderer_render(rtgi_hip_renderer *r, const rtgi_frame *frame, float *framebuffer, uint8_t *rgb8,
                              rtgi_frame_stats *stats);
+
+/* `rt_bench`, driver/main.cpp:50-65: one closest_hit per pixel on camera rays through the pixel centres of `frame`,
+ * timed (the trace call alone, rays already on the GPU), on the first GPU of the renderer. *n_rays = w * h, *ms = wall
+ * time of the call; either may be NULL. The caller's current GPU is left as it was. */
+int rtgi_hip_renderer_rt_bench(rtgi_hip_renderer *r, const rtgi_frame *frame, uint64_t *n_rays, double *ms);
 
 const char *rtgi_hip_renderer_last_error(const rtgi_hip_renderer *r);
 

@@ -85,11 +85,11 @@ public:
 	}
 	// dst[0, bytes) = src[0, bytes), split over the workers and the calling thread; returns when it is done
 	void copy(void *dst, const void *src, size_t bytes) {
-		const size_t parts = workers.size() + 1;
-		if (bytes < (1u << 20) || parts == 1 || !started()) {
+		if (bytes < (1u << 20) || !started()) {  // (started() creates the workers on first use)
 			memcpy(dst, src, bytes);
 			return;
 		}
+		const size_t parts = workers.size() + 1;
 		const size_t piece = ((bytes + parts - 1) / parts + 4095) & ~size_t(4095);
 		{
 			std::lock_guard<std::mutex> lock(guard);
@@ -297,12 +297,9 @@ void read_tunables(rtgi_hip_tracer *h) {
 	h->host_direct = number("RTGI_HIP_HOST_DIRECT", 0, 1, 1) != 0;
 }
 
-int upload(rtgi_hip_tracer *h, const rtgi::SceneView &scene) {
-	rtgi::FlatTree flat;
-	const std::chrono::steady_clock::time_point flatten_begin = std::chrono::steady_clock::now();
-	rtgi::flatten_tree(h->tree, scene, h->cfg.layout, flat);
-	if (getenv("RTGI_HIP_BUILD_TIMES"))
-		fprintf(stderr, "rtgi_hip_build: flatten %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - flatten_begin).count());
+// The GPU form of h->tree (already flattened: `flat`) goes to the handle's GPU, together with what the launches derive
+// from it (division of the LDS, spill area, probe rays).
+int upload_flat(rtgi_hip_tracer *h, const rtgi::FlatTree &flat, const rtgi::SceneView &scene) {
 	if (h->device < 0) return RTGI_OK;
 	DeviceScope device_scope(h->device);
 	HIP_TRY(h, device_scope.status);
@@ -316,7 +313,9 @@ int upload(rtgi_hip_tracer *h, const rtgi::SceneView &scene) {
 	// and the first nodes of the breadth-first numbering in what is left. Deeper trees keep DEEP_STACK_LDS slots
 	// in LDS and the rest of the stack in a global spill area.
 	const uint32_t lds_cu = prop.maxSharedMemoryPerMultiProcessor >= 65536 ? (uint32_t)prop.maxSharedMemoryPerMultiProcessor : 65536u;
-	const uint32_t lds_budget = std::min<uint32_t>(lds_cu / h->blocks_per_cu, 160u << 10);
+	// (what one workgroup may ask for: the opt-in limit where the runtime reports one, else the 64 KiB every GPU grants)
+	const uint32_t lds_block = prop.sharedMemPerBlockOptin >= 65536 ? (uint32_t)prop.sharedMemPerBlockOptin : 65536u;
+	const uint32_t lds_budget = std::min<uint32_t>({lds_cu / h->blocks_per_cu, lds_block, 160u << 10});
 	h->stack_levels = flat.depth <= (uint32_t)rtgi_dev::MAX_STACK_LDS ? std::max<uint32_t>(flat.depth, 1) : (uint32_t)rtgi_dev::DEEP_STACK_LDS;
 	if (h->force_stack_levels) h->stack_levels = (uint32_t)h->force_stack_levels;
 	while (h->stack_levels > 1 && (size_t)h->stack_levels * BLOCK * sizeof(int32_t) > lds_budget) --h->stack_levels;
@@ -387,6 +386,15 @@ int upload(rtgi_hip_tracer *h, const rtgi::SceneView &scene) {
 		}
 	}
 	return RTGI_OK;
+}
+
+int upload(rtgi_hip_tracer *h, const rtgi::SceneView &scene) {
+	rtgi::FlatTree flat;
+	const std::chrono::steady_clock::time_point flatten_begin = std::chrono::steady_clock::now();
+	rtgi::flatten_tree(h->tree, scene, h->cfg.layout, flat);
+	if (getenv("RTGI_HIP_BUILD_TIMES"))
+		fprintf(stderr, "rtgi_hip_build: flatten %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - flatten_begin).count());
+	return upload_flat(h, flat, scene);
 }
 
 // RTGI_HIP_DEBUG_SYNC=1: wait for the stream after every stage and name the stage on stderr, so that a
@@ -495,19 +503,19 @@ int sort_rays(rtgi_hip_tracer *h, const BatchView *batches, uint32_t n_batches, 
 	return RTGI_OK;
 }
 
-// A launch with `lds` bytes of dynamic LDS. More than 64 KiB needs the kernel's limit raised first: once per kernel
-// instantiation and GPU.
+// A launch with `lds` bytes of dynamic LDS. More than 64 KiB needs the kernel's limit raised first, per kernel
+// instantiation and GPU, to what this launch asks for (upload() keeps that within the GPU's per-workgroup limit).
 template <int MODE, bool COUNT, bool DEEP>
 hipError_t launch_kernel(int device, uint32_t blocks, uint32_t lds, hipStream_t stream, const TraceArgs &a) {
 	static std::mutex guard;
-	static bool raised[64] = {};
-	if (device >= 0 && device < 64) {
+	static uint32_t raised[MAX_DEVICES] = {};
+	if (lds > (64u << 10) && device >= 0 && device < MAX_DEVICES) {
 		std::lock_guard<std::mutex> lock(guard);
-		if (!raised[device]) {
+		if (lds > raised[device]) {
 			hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&trace_kernel<MODE, COUNT, DEEP>),
-			                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
+			                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 			if (e != hipSuccess) return e;
-			raised[device] = true;
+			raised[device] = lds;
 		}
 	}
 	hipLaunchKernelGGL((trace_kernel<MODE, COUNT, DEEP>), dim3(blocks), dim3(BLOCK), lds, stream, a);
@@ -822,6 +830,16 @@ int trace_host(rtgi_hip_tracer *h, const rtgi_ray *rays, uint32_t n, void *out) 
 	};
 	// work that earlier calls left on the default stream (the usual place for this handle's launches) comes first
 	HIP_TRY(h, hipStreamSynchronize(nullptr));
+	// Whatever way this call ends, nothing of it is left in flight: copies out of `rays`, kernels that store into
+	// `out` and the slots' events are all reused or released by the caller right after the return.
+	struct Drain {
+		HostPipe &p;
+		~Drain() {
+			(void)hipStreamSynchronize(p.up);
+			(void)hipStreamSynchronize(p.run);
+			(void)hipStreamSynchronize(p.down);
+		}
+	} drain{p};
 	for (uint32_t k = 0; k < n_chunks; ++k) {
 		const int slot = (int)(k % HostPipe::SLOTS);
 		const size_t first = first_of(k);
@@ -1090,6 +1108,70 @@ int rtgi_hip_build(rtgi_hip_tracer *h, const void *vertices, size_t vertex_strid
 		return fail(h, RTGI_ERR_INVALID, "building the BVH failed");
 	}
 }
+
+int rtgi_hip_build_shared(rtgi_hip_tracer *const *handles, uint32_t n_handles, const void *vertices, size_t vertex_stride, uint32_t n_vertices,
+                          const void *triangles, size_t tri_stride, uint32_t n_triangles) {
+	if (!handles || n_handles == 0 || !handles[0]) return RTGI_ERR_INVALID;
+	rtgi_hip_tracer *lead = handles[0];
+	for (uint32_t i = 1; i < n_handles; ++i) {
+		rtgi_hip_tracer *o = handles[i];
+		if (!o) return fail(lead, RTGI_ERR_INVALID, "build_shared: null handle");
+		if (o->cfg.layout != lead->cfg.layout || o->cfg.esc != lead->cfg.esc || o->cfg.split != lead->cfg.split ||
+		    o->cfg.planes != lead->cfg.planes || o->cfg.max_tris != lead->cfg.max_tris)
+			return fail(lead, RTGI_ERR_INVALID, "build_shared: the handles were not given the same layout and bvh settings");
+	}
+	rtgi::SceneView scene;
+	scene.vertices = (const unsigned char *)vertices;
+	scene.vertex_stride = vertex_stride;
+	scene.n_vertices = n_vertices;
+	scene.triangles = (const unsigned char *)triangles;
+	scene.tri_stride = tri_stride;
+	scene.n_triangles = n_triangles;
+	try {
+		std::string err;
+		rtgi::HostTree tree;
+		if (!rtgi::build_tree(lead->cfg, scene, tree, err)) return fail(lead, RTGI_ERR_INVALID, err);
+		rtgi::FlatTree flat;
+		rtgi::flatten_tree(tree, scene, lead->cfg.layout, flat);
+		// every handle keeps the host tree (read-back, `bvh statistics`, shading tables) and uploads the one flat form to
+		// its own GPU, each on a thread of its own: the uploads of different GPUs do not wait for each other
+		std::vector<int> rc(n_handles, RTGI_OK);
+		auto serve = [&](uint32_t i) {
+			rtgi_hip_tracer *h = handles[i];
+			try {
+				if (i + 1 == n_handles)
+					h->tree = std::move(tree);  // (the last one to be served takes the original; see the order below)
+				else
+					h->tree = tree;
+				rc[i] = upload_flat(h, flat, scene);
+				if (rc[i] == RTGI_OK) rc[i] = probe_scene(h);
+			} catch (const std::bad_alloc &) {
+				rc[i] = fail(h, RTGI_ERR_NOMEM, "out of host memory while taking over the BVH");
+			}
+		};
+		std::vector<std::thread> threads;
+		for (uint32_t i = 0; i + 1 < n_handles; ++i) {
+			try {
+				threads.emplace_back(serve, i);
+			} catch (const std::system_error &) {
+				serve(i);  // no thread to be had: one after the other
+			}
+		}
+		for (std::thread &t : threads) t.join();
+		serve(n_handles - 1);  // after the copies have been taken
+		for (uint32_t i = 0; i < n_handles; ++i)
+			if (rc[i] < 0) return i == 0 ? rc[i] : fail(lead, rc[i], "GPU " + std::to_string(handles[i]->device) + ": " + handles[i]->error);
+		return RTGI_OK;
+	} catch (const std::bad_alloc &) {
+		return fail(lead, RTGI_ERR_NOMEM, "out of host memory while building the BVH");
+	} catch (const std::exception &e) {
+		return fail(lead, RTGI_ERR_INVALID, std::string("building the BVH failed: ") + e.what());
+	} catch (...) {
+		return fail(lead, RTGI_ERR_INVALID, "building the BVH failed");
+	}
+}
+
+int rtgi_hip_device_of(const rtgi_hip_tracer *h) { return h ? h->device : -1; }
 
 int rtgi_hip_upload_bvh(rtgi_hip_tracer *h, const rtgi_node56 *nodes, uint32_t n_nodes, uint32_t root,
                         const uint32_t *index, uint32_t n_index, const void *vertices, size_t vertex_stride,

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <new>
@@ -48,6 +49,7 @@ struct Part {
 	rtgi_ray *d_rays[2] = {nullptr, nullptr}, *d_shadow = nullptr;
 	rtgi_hit *d_hits = nullptr, *d_hits2 = nullptr;
 	uint8_t *d_occluded = nullptr, *d_rgb = nullptr;
+	int32_t *d_status = nullptr;  // one process per GPU: the word the ranks agree on before the framebuffer exchange
 };
 
 }  // namespace
@@ -145,6 +147,9 @@ void tile_pixels(int w, int h, uint32_t tile, int world, int rank, std::vector<u
 // This part's share of the frame, up to its framebuffer in place in p.d_full (zero where it has no samples).
 int render_part(Part &p, const rtgi_frame &f, int rank, int world) {
 	PART_HIP(p, hipSetDevice(p.device));
+	// fault injection for the tests of the error paths: RTGI_HIP_FAIL_PART=i makes part (or rank) i fail here
+	if (const char *e = getenv("RTGI_HIP_FAIL_PART"))
+		if (atoi(e) == rank) return fail(p, RTGI_ERR_DEVICE, "failure injected by RTGI_HIP_FAIL_PART");
 	const uint32_t n_full = (uint32_t)f.cam.w * (uint32_t)f.cam.h;
 	const bool by_tiles = world > 1 && f.sharding == RTGI_SHARD_TILES;
 	p.all_pixels = !by_tiles;
@@ -243,6 +248,8 @@ int check_frame(rtgi_hip_renderer *r, const rtgi_frame *f) {
 }
 
 // Runs fn(part index) for every part, on a thread of its own when there are several; a part's failure is kept in it.
+// fn must not enter a collective: a part that fails early would leave its peers waiting inside one. (The framebuffer
+// exchange is issued for all parts by one thread, see exchange_in_process.)
 template <class F>
 int for_each_part(rtgi_hip_renderer *r, F fn) {
 	const int n = (int)r->parts.size();
@@ -257,21 +264,90 @@ int for_each_part(rtgi_hip_renderer *r, F fn) {
 			fail(r->parts[(size_t)i], RTGI_ERR_NOMEM, "exception");
 		}
 	};
-	if (n == 1)
-		guarded(0);
-	else {
-		std::vector<std::thread> threads;
+	std::vector<std::thread> threads;
+	for (int i = 1; i < n; ++i) {
 		try {
-			for (int i = 1; i < n; ++i) threads.emplace_back([&guarded, i] { guarded(i); });
-		} catch (const std::exception &e) {
-			for (std::thread &t : threads) t.join();
-			return fail(r, RTGI_ERR_NOMEM, std::string("cannot start a host thread per GPU: ") + e.what());
+			threads.emplace_back([&guarded, i] { guarded(i); });
+		} catch (const std::exception &) {
+			guarded(i);  // no thread to be had: this part takes its turn on the calling thread
 		}
-		guarded(0);
-		for (std::thread &t : threads) t.join();
 	}
+	guarded(0);
+	for (std::thread &t : threads) t.join();
 	for (int i = 0; i < n; ++i)
 		if (r->parts[i].rc < 0) return fail(r, r->parts[i].rc, "GPU " + std::to_string(r->parts[i].device) + " (part " + std::to_string(i) + "): " + r->parts[i].error);
+	return RTGI_OK;
+}
+
+// After a collective went wrong nothing can be said about the communicators' state: they are given up (ncclCommAbort
+// also ends collectives that are still waiting for ranks that never came) and the next frame starts new ones.
+void abort_comms(rtgi_hip_renderer *r) {
+	for (Part &p : r->parts)
+		if (p.comm) {
+			(void)ncclCommAbort(p.comm);
+			p.comm = nullptr;
+		}
+	r->comms_ready = false;
+}
+
+// All GPUs in this process: the all-reduce of every part is issued by ONE thread inside an RCCL group, after everything
+// that can be checked has been checked, so either all parts enter the collective or none does.
+int exchange_in_process(rtgi_hip_renderer *r, uint32_t n_full) {
+	for (const Part &p : r->parts)
+		if (!p.comm || !p.d_full || !p.stream) return fail(r, RTGI_ERR_DEVICE, "framebuffer exchange: a part has no communicator, buffer or stream");
+	ncclResult_t first_bad = ncclGroupStart();
+	if (first_bad != ncclSuccess) return fail(r, RTGI_ERR_DEVICE, std::string("ncclGroupStart: ") + ncclGetErrorString(first_bad));
+	for (Part &p : r->parts) {
+		first_bad = ncclAllReduce(p.d_full, p.d_full, (size_t)n_full * 4, ncclFloat, ncclSum, p.comm, p.stream);
+		if (first_bad != ncclSuccess) break;
+	}
+	const ncclResult_t ended = ncclGroupEnd();
+	if (first_bad != ncclSuccess || ended != ncclSuccess) {
+		const std::string what = std::string("ncclAllReduce: ") + ncclGetErrorString(first_bad != ncclSuccess ? first_bad : ended);
+		abort_comms(r);
+		return fail(r, RTGI_ERR_DEVICE, what);
+	}
+	// every part has entered: all of them are waited for, whatever the others report
+	std::string bad;
+	for (Part &p : r->parts) {
+		hipError_t e = hipSetDevice(p.device);
+		if (e == hipSuccess) e = hipStreamSynchronize(p.stream);
+		if (e != hipSuccess && bad.empty()) bad = "GPU " + std::to_string(p.device) + " after ncclAllReduce: " + hipGetErrorString(e);
+	}
+	if (!bad.empty()) {
+		abort_comms(r);
+		return fail(r, RTGI_ERR_DEVICE, bad);
+	}
+	return RTGI_OK;
+}
+
+// One process per GPU: render() is a collective call, and a rank must not stay away from a collective its peers
+// enter. Every rank therefore first takes part in a one-word all-reduce (max) of "my part failed", whatever happened
+// to its own part; only if nobody failed do all of them go on to the framebuffer. local_rc: this rank's own result.
+int exchange_by_rank(rtgi_hip_renderer *r, uint32_t n_full, int local_rc) {
+	Part &p = r->parts[0];
+	if (!p.comm || !p.d_status) return fail(r, RTGI_ERR_DEVICE, "the communicator was given up after an earlier failure: create the renderer again on all ranks");
+	const std::string local_error = r->error;
+	int32_t status = local_rc < 0 ? 1 : 0;
+	auto lost = [&](const std::string &what) {
+		abort_comms(r);
+		return fail(r, RTGI_ERR_DEVICE, what + (local_rc < 0 ? " (after: " + local_error + ")" : std::string()));
+	};
+	hipError_t e = hipSetDevice(p.device);
+	if (e == hipSuccess) e = hipMemcpyAsync(p.d_status, &status, sizeof(status), hipMemcpyHostToDevice, p.stream);
+	if (e != hipSuccess) return lost(std::string("status exchange: ") + hipGetErrorString(e));
+	ncclResult_t ne = ncclAllReduce(p.d_status, p.d_status, 1, ncclInt32, ncclMax, p.comm, p.stream);
+	if (ne != ncclSuccess) return lost(std::string("status exchange, ncclAllReduce: ") + ncclGetErrorString(ne));
+	e = hipMemcpyAsync(&status, p.d_status, sizeof(status), hipMemcpyDeviceToHost, p.stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(p.stream);
+	if (e != hipSuccess) return lost(std::string("status exchange: ") + hipGetErrorString(e));
+	if (local_rc < 0) return local_rc;  // (r->error still has this rank's own text)
+	if (status != 0) return fail(r, RTGI_ERR_DEVICE, "another rank failed to render its part of the frame");
+	if (!p.d_full) return lost("framebuffer exchange: no buffer");
+	ne = ncclAllReduce(p.d_full, p.d_full, (size_t)n_full * 4, ncclFloat, ncclSum, p.comm, p.stream);
+	if (ne != ncclSuccess) return lost(std::string("ncclAllReduce: ") + ncclGetErrorString(ne));
+	e = hipStreamSynchronize(p.stream);
+	if (e != hipSuccess) return lost(std::string("after ncclAllReduce: ") + hipGetErrorString(e));
 	return RTGI_OK;
 }
 
@@ -299,6 +375,16 @@ rtgi_hip_renderer *rtgi_hip_renderer_create(const int *devices, int n, int layou
 	for (int i = 0; i < n; ++i)
 		for (int j = 0; j < i; ++j)
 			if (devices[i] == devices[j]) r->distinct = false;
+	// (the caller's current GPU is the caller's business: it is put back on every way out)
+	struct KeepDevice {
+		int was = -1;
+		KeepDevice() {
+			if (hipGetDevice(&was) != hipSuccess) was = -1, (void)hipGetLastError();
+		}
+		~KeepDevice() {
+			if (was >= 0) (void)hipSetDevice(was);
+		}
+	} keep_device;
 	for (int i = 0; i < n; ++i) {
 		Part &p = r->parts[(size_t)i];
 		p.device = devices[i];
@@ -352,6 +438,12 @@ rtgi_hip_renderer *rtgi_hip_renderer_create_rank(int device, int layout, int esc
 		rtgi_hip_renderer_destroy(r);
 		return nullptr;
 	}
+	he = hipMalloc((void **)&p.d_status, 256);
+	if (he != hipSuccess) {
+		g_create_error = std::string("hipMalloc: ") + hipGetErrorString(he);
+		rtgi_hip_renderer_destroy(r);
+		return nullptr;
+	}
 	r->comms_ready = true;
 	return r;
 }
@@ -360,6 +452,7 @@ void rtgi_hip_renderer_destroy(rtgi_hip_renderer *r) {
 	if (!r) return;
 	for (Part &p : r->parts) {
 		free_buffers(p);
+		if (p.d_status) (void)hipFree(p.d_status);
 		if (p.comm) (void)ncclCommDestroy(p.comm);
 		if (p.stream && hipSetDevice(p.device) == hipSuccess) (void)hipStreamDestroy(p.stream);
 		if (p.h) rtgi_hip_destroy(p.h);
@@ -392,12 +485,17 @@ int rtgi_hip_renderer_build(rtgi_hip_renderer *r, const void *vertices, size_t v
 	if (!r) return RTGI_ERR_INVALID;
 	if (!vertices || !triangles) return fail(r, RTGI_ERR_INVALID, "there is no scene data to work with");
 	if (vertex_stride < 24 || tri_stride < 16) return fail(r, RTGI_ERR_INVALID, "renderer_build: vertex records need position and normal, triangle records a material id");
+	// one tree for all GPUs: built and flattened once, uploaded to each (rtgi_hip_build_shared); then every part
+	// derives its shading tables
+	std::vector<rtgi_hip_tracer *> handles;
+	for (Part &p : r->parts) handles.push_back(p.h);
+	const int brc = rtgi_hip_build_shared(handles.data(), (uint32_t)handles.size(), vertices, vertex_stride, n_vertices, triangles, tri_stride, n_triangles);
+	if (brc < 0) return fail(r, brc, rtgi_hip_last_error(handles[0]));
+	if (!albedo_rgb || !n_materials) return RTGI_OK;
 	return for_each_part(r, [&](int i) {
 		Part &p = r->parts[(size_t)i];
-		int rc = rtgi_hip_build(p.h, vertices, vertex_stride, n_vertices, triangles, tri_stride, n_triangles);
-		if (rc == RTGI_OK && albedo_rgb && n_materials)
-			rc = rtgi_hip_set_shading(p.h, (const char *)vertices + 12, vertex_stride, n_vertices, triangles, tri_stride, n_triangles, albedo_rgb,
-			                          n_materials);
+		const int rc = rtgi_hip_set_shading(p.h, (const char *)vertices + 12, vertex_stride, n_vertices, triangles, tri_stride, n_triangles, albedo_rgb,
+		                                    n_materials);
 		if (rc < 0) fail(p, rc, rtgi_hip_last_error(p.h));
 	});
 }
@@ -455,29 +553,20 @@ int render_frame(rtgi_hip_renderer *r, const rtgi_frame *frame, float *framebuff
 		r->comms_ready = true;
 	}
 	int rc = for_each_part(r, [&](int i) { render_part(r->parts[(size_t)i], f, by_rank ? r->world_rank : i, world); });
-	if (rc) return rc;
+	// All parts of this process have come back. In-process: if any failed, none enters the exchange. By rank: the
+	// other processes cannot know yet, see exchange_by_rank.
+	if (rc && !by_rank) return rc;
 	double t_traced = t0;
 	for (const Part &p : r->parts) t_traced = std::max(t_traced, p.t_traced);
 	// ---- the one exchange of a frame: framebuffers as sums and counts (tiles: every pixel has one owner, the
 	// others hold zeros, and x + 0 = x keeps the owner's value to the bit) ----
 	bool used_rccl = false;
 	if (world > 1 || by_rank) {
-		if (r->distinct) {
-			rc = for_each_part(r, [&](int i) {
-				Part &p = r->parts[(size_t)i];
-				if (hipSetDevice(p.device) != hipSuccess) {
-					fail(p, RTGI_ERR_DEVICE, "hipSetDevice");
-					return;
-				}
-				const ncclResult_t e = ncclAllReduce(p.d_full, p.d_full, (size_t)n_full * 4, ncclFloat, ncclSum, p.comm, p.stream);
-				if (e != ncclSuccess) {
-					fail(p, RTGI_ERR_DEVICE, std::string("ncclAllReduce: ") + ncclGetErrorString(e));
-					return;
-				}
-				const hipError_t he = hipStreamSynchronize(p.stream);
-				if (he != hipSuccess) fail(p, RTGI_ERR_DEVICE, std::string("after ncclAllReduce: ") + hipGetErrorString(he));
-			});
-			if (rc) return rc;
+		if (by_rank) {
+			if ((rc = exchange_by_rank(r, n_full, rc)) != RTGI_OK) return rc;
+			used_rccl = true;
+		} else if (r->distinct) {
+			if ((rc = exchange_in_process(r, n_full)) != RTGI_OK) return rc;
 			used_rccl = true;
 		} else {
 			// handles that share a GPU (a rehearsal of the multi-GPU path): the same sum by a kernel on that GPU
@@ -517,6 +606,39 @@ int render_frame(rtgi_hip_renderer *r, const rtgi_frame *frame, float *framebuff
 	return RTGI_OK;
 }
 }  // namespace
+
+int rtgi_hip_renderer_rt_bench(rtgi_hip_renderer *r, const rtgi_frame *frame, uint64_t *n_rays, double *ms) {
+	if (!r) return RTGI_ERR_INVALID;
+	if (int rc = check_frame(r, frame)) return rc;
+	Part &p = r->parts[0];
+	const size_t n = (size_t)frame->cam.w * (size_t)frame->cam.h;
+	// everything below lives on part 0's GPU: buffers, launches and the waits that bracket the timing
+	int was = -1;
+	if (hipGetDevice(&was) != hipSuccess) was = -1;
+	hipError_t e = hipSetDevice(p.device);
+	rtgi_ray *d_rays = nullptr;
+	rtgi_hit *d_hits = nullptr;
+	if (e == hipSuccess) e = hipMalloc((void **)&d_rays, n * sizeof(rtgi_ray));
+	if (e == hipSuccess) e = hipMalloc((void **)&d_hits, n * sizeof(rtgi_hit));
+	int rc = RTGI_OK;
+	double elapsed = 0.0;
+	if (e == hipSuccess) rc = rtgi_hip_camera_rays_device(p.h, &frame->cam, nullptr, d_rays, p.stream);
+	if (e == hipSuccess && rc == RTGI_OK) e = hipStreamSynchronize(p.stream);
+	if (e == hipSuccess && rc == RTGI_OK) {
+		const double t0 = now_ms();
+		rc = rtgi_hip_closest_hit_device(p.h, d_rays, (uint32_t)n, d_hits, nullptr, p.stream);
+		if (rc == RTGI_OK) e = hipStreamSynchronize(p.stream);
+		elapsed = now_ms() - t0;
+	}
+	if (d_rays) (void)hipFree(d_rays);
+	if (d_hits) (void)hipFree(d_hits);
+	if (was >= 0) (void)hipSetDevice(was);
+	if (rc < 0) return fail(r, rc, rtgi_hip_last_error(p.h));
+	if (e != hipSuccess) return fail(r, RTGI_ERR_DEVICE, std::string("rt_bench: ") + hipGetErrorString(e));
+	if (n_rays) *n_rays = n;
+	if (ms) *ms = elapsed;
+	return RTGI_OK;
+}
 
 const char *rtgi_hip_renderer_last_error(const rtgi_hip_renderer *r) { return r ? r->error.c_str() : g_create_error.c_str(); }
 

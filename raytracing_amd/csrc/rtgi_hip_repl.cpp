@@ -15,9 +15,8 @@
 // (`seq`, `naive-bvh`, `bbvh [indexed] [esc]`) are accepted and create the same GPU tracer with the layout asked for,
 // so that the reference's scripts run unchanged. Host-side only: OBJ/MTL reading, PNG textures, the material table and
 // the PNG file (the reference uses assimp, MagickWand and png++, none of which this program needs; zlib inflates).
-#include <hip/hip_runtime_api.h>
-
 #include <algorithm>
+#include <cctype>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -425,6 +424,8 @@ struct Options {
 	bool interact = true, outfile_from_cmdline = false, dry_run = false, strict = false;
 };
 
+struct Line;
+
 struct Repl {
 	Options opt;
 	Scene scene;
@@ -484,6 +485,10 @@ struct Repl {
 		return "";
 	}
 
+	void print_timers() const {
+		for (const auto &t : timers) std::cout << t.first << ": " << t.second.first << " ms in " << t.second.second << " call(s)" << std::endl;
+	}
+
 	void note_time(const std::string &what, std::chrono::steady_clock::time_point t0) {
 		auto &t = timers[what];
 		t.first += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -520,362 +525,457 @@ struct Repl {
 
 	// rt_bench, driver/main.cpp:50-65: closest_hit on one frame of camera rays through pixel centres, timed
 	std::string rt_bench() {
-		rtgi_hip_tracer *h = rtgi_hip_renderer_handle(renderer, 0);
 		const rtgi_frame f = frame();
-		const size_t n = (size_t)scene.w * scene.h;
-		rtgi_ray *d_rays = nullptr;
-		rtgi_hit *d_hits = nullptr;
-		if (hipMalloc((void **)&d_rays, n * sizeof(rtgi_ray)) != hipSuccess || hipMalloc((void **)&d_hits, n * sizeof(rtgi_hit)) != hipSuccess) {
-			if (d_rays) (void)hipFree(d_rays);
-			return "out of GPU memory";
-		}
-		std::string err;
-		if (rtgi_hip_camera_rays_device(h, &f.cam, nullptr, d_rays, nullptr) < 0 || hipDeviceSynchronize() != hipSuccess) err = rtgi_hip_last_error(h);
-		if (err.empty()) {
-			const auto t0 = std::chrono::steady_clock::now();
-			if (rtgi_hip_closest_hit_device(h, d_rays, (uint32_t)n, d_hits, nullptr, nullptr) < 0 || hipDeviceSynchronize() != hipSuccess)
-				err = rtgi_hip_last_error(h);
-			const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-			note_time("rt_bench", t0);
-			if (err.empty()) std::cout << "rt_bench: " << n << " rays in " << ms << " ms (" << (double)n / (ms * 1e3) << " Mrays/s)" << std::endl;
-		}
-		(void)hipFree(d_rays), (void)hipFree(d_hits);
-		return err;
+		uint64_t n = 0;
+		double ms = 0.0;
+		const auto t0 = std::chrono::steady_clock::now();
+		if (rtgi_hip_renderer_rt_bench(renderer, &f, &n, &ms) < 0) return rtgi_hip_renderer_last_error(renderer);
+		note_time("rt_bench", t0);
+		std::cout << "rt_bench: " << n << " rays in " << ms << " ms (" << (double)n / (ms * 1e3) << " Mrays/s)" << std::endl;
+		return "";
 	}
 
-	void loop(std::istream &infile, bool prompt);
+	// ---- the command interpreter: one table of commands, one small function per command ----
+	// State that outlives a line.
+	bool camera_up_given = false, scene_up_given = false, leave = false;
+	std::string selected_material;  // by name: `load` may move the material table
+	std::vector<std::string> journal;  // every line read so far (`history`)
+	int line_no = 0;
+
+	void interpret(const std::string &text);
+	void read_commands(std::istream &input, bool prompt);
+
+	Material *material_named(const std::string &name) {
+		for (Material &m : scene.materials)
+			if (m.name == name) return &m;
+		return nullptr;
+	}
+	void require_gpu_state(bool for_bench) const;
+
+	// handlers (the grammar is that of driver/interaction.cpp:81-404; see the table below for who serves what)
+	void cmd_camera_vector(const Line &l);
+	void cmd_scene_up(const Line &l);
+	void cmd_load(const Line &l);
+	void cmd_resolution(const Line &l);
+	void cmd_algo(const Line &l);
+	void cmd_bounces(const Line &l);
+	void cmd_outfile(const Line &l);
+	void cmd_raytracer(const Line &l);
+	void cmd_commit(const Line &l);
+	void cmd_sppx(const Line &l);
+	void cmd_run(const Line &l);
+	void cmd_mesh(const Line &l);
+	void cmd_material(const Line &l);
+	void cmd_default_brdf(const Line &l);
+	void cmd_pointlight(const Line &l);
+	void cmd_omp(const Line &l);
+	void cmd_stats(const Line &l);
+	void cmd_echo(const Line &l);
+	void cmd_history(const Line &l);
+	void cmd_leave(const Line &l);
+	void cmd_backend(const Line &l);
 };
 
-#define error(x)                                                                                 \
-	{                                                                                            \
-		std::cerr << "command " << cmdid << " (" << command << "): " << x << std::endl;         \
-		++errors;                                                                                \
-		continue;                                                                                \
-	}
-#define check_in(x) \
-	if (in.bad() || in.fail()) error(x)
-#define check_in_complete(x) \
-	if (in.bad() || in.fail() || !in.eof()) error(x)
+// A command that cannot be carried out: reported on stderr with the line it came from, the script goes on.
+struct Refused {
+	std::string why;
+};
+[[noreturn]] void refuse(const std::string &why) { throw Refused{why}; }
 
-void Repl::loop(std::istream &infile, bool prompt) {
-	bool cam_has_up = false, scene_up_set = false;
-	Material *mat = nullptr;
-	std::string mat_name;
-	std::vector<std::string> commands;
-	while (!infile.eof()) {
-		if (prompt) std::cout << "rtgi > " << std::flush;
-		cmdid++;
-		std::string line, command;
-		std::getline(infile, line);
-		while (!line.empty() && (line.back() == '\r' || line.back() == ' ' || line.back() == '\t')) line.pop_back();
-		commands.push_back(line);
-		std::istringstream in(line);
-		in >> command;
-		vec3 tmp;
-		if (command == "history") {
-			commands.pop_back();
-			for (auto &x : commands) std::cout << x << std::endl;
-		} else if (command == "quit" || command == "exit")
-			return;
-		else if (command == "at" || command == "look" || command == "camup") {
-			vec3 &target = command == "at" ? scene.cam_pos : command == "look" ? scene.cam_dir : scene.cam_up;
-			in.get();
-			if (in.eof()) {
-				std::cout << target << std::endl;
-				continue;
-			}
-			in >> tmp;
-			check_in_complete("Syntax error, requires 3 numerical components");
-			target = tmp;
-			if (command == "camup") cam_has_up = true;
-		} else if (command == "up") {
-			in.get();
-			if (in.eof() && scene_up_set) {
-				std::cout << scene.up << std::endl;
-				continue;
-			}
-			if (scene_up_set) error("Cannot set scene up vector twice, did you mean camup?");
-			in >> tmp;
-			check_in_complete("Syntax error, requires 3 numerical components");
-			scene_up_set = true;
-			scene.up = tmp;
-			if (!cam_has_up) {
-				scene.cam_up = scene.up;
-				cam_has_up = true;
-			}
-		} else if (command == "load") {
-			std::string file, name;
-			in >> file;
-			if (!in.eof()) in >> name;
-			check_in_complete("Syntax error, requires a file name (no spaces, sorry) and (optionally) a name");
-			mat = nullptr;  // (the material table may move)
-			const std::string err = load_obj(scene, file, name);
-			if (!err.empty()) error(err);
-			if (!mat_name.empty())
-				for (auto &m : scene.materials)
-					if (m.name == mat_name) mat = &m;
-			scene_touched_at = cmdid;
-		} else if (command == "resolution") {
-			int w, h;
-			in >> w >> h;
-			check_in_complete("Syntax error, requires 2 integral values");
-			if (w <= 0 || h <= 0) error("Resolution must be positive");
-			scene.w = w, scene.h = h;
-		} else if (command == "algo") {
-			std::string name;
-			in >> name;
-			if (name == "primary")
-				algo = RTGI_ALGO_PRIMARY;
-			else if (name == "local")
-				algo = RTGI_ALGO_LOCAL;
-			else if (name == "path")  // this backend's own: diffuse paths, `bounces N` segments after the camera ray
-				algo = RTGI_ALGO_PATH;
-			else
-				error("There is no gi algorithm called '" << name << "'");
-		} else if (command == "bounces") {
-			int n;
-			in >> n;
-			check_in_complete("Syntax error, requires exactly one non-negative integral value");
-			if (n < 0 || n > 64) error("Between 0 and 64 bounces");
-			bounces = (unsigned)n;
-		} else if (command == "outfile") {
-			std::string name;
-			in >> name;
-			check_in_complete("Syntax error, only accepts a single file name (no spaces, sorry)");
-			if (!opt.outfile_from_cmdline) opt.outfile = name;  // "cmdline options should supersede the script's"
-		} else if (command == "raytracer") {
-			std::string name;
-			in >> name;
-			std::vector<std::string> tags;
-			for (std::string t; in >> t;) tags.push_back(t);
-			bool flat = true, esc = false;
-			std::vector<int> devices = {0};
-			if (name == "seq" || name == "naive-bvh") {
-				if (!tags.empty()) error("There is no such variant");
-				std::cout << "note: '" << name << "' is served by the hip tracer (flat layout)" << std::endl;
-			} else if (name == "bbvh" || name == "hip") {
-				bool bad = false;
-				for (size_t k = 0; k < tags.size(); ++k) {
-					if (tags[k] == "indexed")
-						flat = false;
-					else if (tags[k] == "esc")
-						esc = true;
-					else if (tags[k] == "devices" && name == "hip" && k + 1 < tags.size()) {
-						const std::string &spec = tags[++k];
-						devices.clear();
-						if (spec.find(',') == std::string::npos) {
-							const int n = std::atoi(spec.c_str());
-							for (int d = 0; d < n; ++d) devices.push_back(d);
-						} else {
-							std::istringstream ds(spec);
-							for (std::string d; std::getline(ds, d, ',');) devices.push_back(std::atoi(d.c_str()));
-						}
-						if (devices.empty() || devices.size() > 64) bad = true;
-					} else if (name == "hip")
-						bad = true;  // (the reference ignores unknown bbvh tags)
-				}
-				if (bad) error("Syntax error: raytracer hip [indexed] [esc] [devices N | devices a,b,...]");
-				if (flat && esc) error("This combination is technically problematic");
-			} else
-				error("There is no ray tracer called '" << name << "'");
-			if (!opt.dry_run) {
-				rtgi_hip_renderer *r = rtgi_hip_renderer_create(devices.data(), (int)devices.size(), flat ? RTGI_LAYOUT_FLAT : RTGI_LAYOUT_INDEXED, esc ? 1 : 0);
-				if (!r) error(rtgi_hip_renderer_last_error(nullptr));
-				if (renderer) rtgi_hip_renderer_destroy(renderer);
-				renderer = r;
-			}
-			tracer_desc = name;
-			tracer_touched_at = cmdid;
-		} else if (command == "commit") {
-			if (scene.vertices.empty()) error("There is no scene data to work with");
-			if (tracer_touched_at == 0) error("There is no ray traversal scheme to commit the scene data to");
-			if (!opt.dry_run) {
-				const std::string err = commit();
-				if (!err.empty()) error(err);
-			}
-			accel_touched_at = cmdid;
-		} else if (command == "sppx") {
-			int n;
-			in >> n;
-			check_in_complete("Syntax error, requires exactly one positive integral value");
-			if (n <= 0) error("Syntax error, requires exactly one positive integral value");
-			sppx = (unsigned)n;
-		} else if (command == "run" || command == "rt_bench") {
-			const bool bench = command == "rt_bench";
-			if (scene_touched_at == 0 || tracer_touched_at == 0 || accel_touched_at == 0 || (!bench && algo < 0))
-				error("We have to have a scene loaded, a ray tracer set, an acceleration structure built" << (bench ? "" : " and an algorithm set") << " prior to running");
-			if (accel_touched_at < tracer_touched_at) error("The current tracer does (might?) not have an up-to-date acceleration structure");
-			if (accel_touched_at < scene_touched_at) error("The current acceleration structure is out-dated");
-			if (!bench && algo != RTGI_ALGO_PRIMARY && !scene.have_light) error("There is no light: pointlight pos x y z col r g b");
-			if (opt.dry_run) continue;
-			const std::string err = bench ? rt_bench() : run();
-			if (!err.empty()) error(err);
-		} else if (command == "mesh") {
-			std::string name;
-			in >> name;
-			if (in.eof() && name == "list") {
-				for (auto &obj : scene.objects) std::cout << obj.name << std::endl;
-				continue;
-			}
-			error("Meshes can only be listed in this version");
-		} else if (command == "material") {
-			std::string cmd;
-			in >> cmd;
-			if (in.eof() && cmd == "list") {
-				for (auto &mtl : scene.materials) std::cout << mtl.name << std::endl;
-				continue;
-			}
-			check_in("Syntax error, requires material name, command and subsequent arguments");
-			command = cmd;
-			if (command == "select") {
-				std::string name;
-				in >> name;
-				check_in_complete("Only a single string (no whitespace) accepted");
-				Material *m = nullptr;
-				for (auto &mtl : scene.materials)
-					if (mtl.name == name) {
-						m = &mtl;
-						break;
-					}
-				if (!m) error("No material called '" << name << "'");
-				mat = m, mat_name = name;
-				continue;
-			}
-			if (!mat) error("No material selected");
-			if (command == "albedo") {
-				in >> tmp;
-				check_in_complete("Expects a color triplet");
-				mat->albedo = tmp;
-			} else if (command == "emissive") {
-				in >> tmp;
-				check_in_complete("Expects a color triplet");
-				mat->emissive = tmp;
-			} else if (command == "roughness") {
-				in >> tmp.x;
-				check_in_complete("Expects a floating point value");
-				mat->roughness = tmp.x;
-			} else if (command == "ior") {
-				in >> tmp.x;
-				check_in_complete("Expects a floating point value");
-				mat->ior = tmp.x;
-			} else if (command == "texture") {
-				in >> cmd;
-				check_in_complete("Expected a single (no whitespace) string value");
-				// (the textures stay around: other materials might still use them, driver/interaction.cpp:293-294)
-				if (cmd == "drop")
-					mat->texture = -1;
-				else {
-					std::string err;
-					const int t = load_image3f(scene.textures, cmd, err);
-					if (t < 0) error(err);
-					mat->texture = t, mat->texture_path = cmd;
-				}
-			} else if (command == "brdf") {
-				in >> cmd;
-				check_in_complete("Expected a single (no whitespace) string value");
-				const int k = cmd == "default" ? (int)scene.default_brdf : brdf_by_name(cmd);
-				if (k < 0) error("No such brdf defined: " << cmd);
-				mat->brdf = (uint32_t)k;
-			} else if (command == "show") {
-				check_in_complete("Does not take further arguments");
-				std::cout << "albedo     " << mat->albedo << std::endl;
-				std::cout << "albedo-tex " << (mat->texture < 0 ? std::string("none") : scene.textures[(size_t)mat->texture].path) << std::endl;
-				std::cout << "emissive   " << mat->emissive << std::endl;
-				std::cout << "roughness  " << mat->roughness << std::endl;
-				std::cout << "ior        " << mat->ior << std::endl;
-				std::cout << "brdf       " << BRDF_NAMES[mat->brdf] << std::endl;
-			} else
-				error("Unknown subcommand");
-		} else if (command == "default-brdf") {
-			std::string name;
-			in >> name;
-			check_in_complete("Expected a single (no whitespace) string value");
-			if (scene.default_brdf_set && !scene.materials.empty())
-				std::cout << "Replacing default brdfs that has already been applied to some materials." << std::endl;
-			const int k = brdf_by_name(name);
-			if (k < 0) error("No such brdf defined: " << name);
-			scene.default_brdf = (uint32_t)k;  // (materials loaded from now on get it, libgi/scene.cpp:136)
-			scene.default_brdf_set = true;
-		} else if (command == "pointlight") {
-			vec3 p, c;
-			std::string cmd;
-			in >> cmd;
-			check_in("Command incomplete");
-			bool replace = false;
-			if (cmd == "replace") {
-				replace = true;
-				in >> cmd;
-				check_in("Command incomplete");
-			}
-			if (cmd == "pos")
-				in >> p;
-			else
-				error("Syntax error: poinlight [replace] pos x y z col x y z");
-			check_in("Syntax error: poinlight [replace] pos x y z col x y z");
-			in >> cmd;
-			check_in("Command incomplete");
-			if (cmd == "col")
-				in >> c;
-			else
-				error("Syntax error: poinlight [replace] pos x y z col x y z");
-			check_in_complete("Syntax error: poinlight [replace] pos x y z col x y z");
-			// local_illumination reads lights[0] only (gi/primary-hit.cpp:41): a further light without `replace` is kept out
-			if (scene.have_light && !replace) {
-				std::cout << "note: only the first point light is used (as by the reference's algorithms); use 'pointlight replace ...'" << std::endl;
-				continue;
-			}
-			scene.light_pos = p, scene.light_col = c, scene.have_light = true;
-		} else if (command == "omp") {
-			std::string sub;
-			in >> sub;
-			if (sub != "on" && sub != "off") error("Syntax error: expected 'on' or 'off'");
-			// (no host threads trace here)
-		} else if (command == "stats") {
-			std::string sub;
-			in >> sub;
-			if (sub == "clear")
-				timers.clear();
-			else if (sub == "print")
-				for (auto &t : timers) std::cout << t.first << ": " << t.second.first << " ms in " << t.second.second << " call(s)" << std::endl;
-			else
-				error("No such stats subcommand");
-		} else if (command == "echo") {
-			std::string text;
-			in >> std::ws;  // (the reference skips the blank with `in >> c`, which also eats the first letter)
-			std::getline(in, text);
-			std::cout << text << std::endl;
-		} else if (command == "" || command[0] == '#')
-			;
-		else if (command == "hip" || command == "bvh") {
-			std::string rest;
-			std::getline(in, rest);
-			std::istringstream sub(rest);
-			std::string what;
-			sub >> what;
-			if (command == "hip" && (what == "sharding" || what == "tile" || what == "seed" || what == "jitter")) {
-				std::string arg;
-				sub >> arg;
-				if (what == "sharding" && (arg == "tiles" || arg == "samples"))
-					sharding = arg == "tiles" ? RTGI_SHARD_TILES : RTGI_SHARD_SAMPLES;
-				else if (what == "tile" && std::atoi(arg.c_str()) > 0)
-					tile = (unsigned)std::atoi(arg.c_str());
-				else if (what == "seed" && !arg.empty())
-					seed = (unsigned)std::strtoul(arg.c_str(), nullptr, 10);
-				else if (what == "jitter" && (arg == "on" || arg == "off"))
-					jitter = arg == "on";
-				else
-					error("Syntax error: hip sharding tiles|samples, hip tile N, hip seed N, hip jitter on|off");
-				continue;
-			}
-			if (tracer_touched_at == 0) error("Unknown command");
-			if (opt.dry_run) continue;
-			const int rc = rtgi_hip_renderer_interprete(renderer, command.c_str(), rest.c_str());
-			if (rc < 0) error(rtgi_hip_renderer_last_error(renderer));
-			if (rc == 0) error("Unknown command");
-		} else
-			error("Unknown command");
+bool whole_float(const std::string &s, float &v) {
+	if (s.empty()) return false;
+	char *stop = nullptr;
+	v = std::strtof(s.c_str(), &stop);
+	return stop && *stop == '\0';
+}
+bool whole_int(const std::string &s, long &v) {
+	if (s.empty()) return false;
+	char *stop = nullptr;
+	v = std::strtol(s.c_str(), &stop, 10);
+	return stop && *stop == '\0';
+}
+
+// One input line cut into blank-separated words; word[0] is the command.
+struct Line {
+	std::string text;
+	std::vector<std::string> word;
+	std::vector<size_t> begin;  // where each word starts in text
+	explicit Line(const std::string &t) : text(t) {
+		size_t at = 0;
+		while (at < text.size()) {
+			while (at < text.size() && std::isspace((unsigned char)text[at])) ++at;
+			if (at == text.size()) break;
+			const size_t from = at;
+			while (at < text.size() && !std::isspace((unsigned char)text[at])) ++at;
+			word.push_back(text.substr(from, at - from));
+			begin.push_back(from);
+		}
 	}
-	std::cout << std::endl;
+	size_t args() const { return word.empty() ? 0 : word.size() - 1; }
+	const std::string &arg(size_t i) const {
+		static const std::string none;
+		return i + 1 < word.size() ? word[i + 1] : none;
+	}
+	// everything after the first n arguments, blanks inside kept
+	std::string tail(size_t n) const { return n + 1 < word.size() ? text.substr(begin[n + 1]) : std::string(); }
+	float real(size_t i, const char *what) const {
+		float v;
+		if (!whole_float(arg(i), v)) refuse(std::string(what) + ": '" + arg(i) + "' is not a number");
+		return v;
+	}
+	long integer(size_t i, const char *what) const {
+		long v;
+		if (!whole_int(arg(i), v)) refuse(std::string(what) + ": '" + arg(i) + "' is not a whole number");
+		return v;
+	}
+	vec3 triple(size_t first, const char *what) const {
+		vec3 v;
+		v.x = real(first, what), v.y = real(first + 1, what), v.z = real(first + 2, what);
+		return v;
+	}
+};
+
+struct CommandEntry {
+	const char *name;
+	int least, most;  // number of arguments accepted (most < 0: any)
+	const char *usage;
+	void (Repl::*serve)(const Line &);
+};
+// The command surface. Names, argument order and meaning follow the renderer's scripts (driver/interaction.cpp:81-404);
+// `bounces`, `hip ...` and `algo path` are this backend's additions.
+const CommandEntry COMMANDS[] = {
+    {"at", 0, 3, "at [x y z]", &Repl::cmd_camera_vector},
+    {"look", 0, 3, "look [x y z]", &Repl::cmd_camera_vector},
+    {"camup", 0, 3, "camup [x y z]", &Repl::cmd_camera_vector},
+    {"up", 0, 3, "up [x y z]", &Repl::cmd_scene_up},
+    {"load", 1, 2, "load file.obj [name]", &Repl::cmd_load},
+    {"resolution", 2, 2, "resolution width height", &Repl::cmd_resolution},
+    {"algo", 1, 1, "algo primary|local|path", &Repl::cmd_algo},
+    {"bounces", 1, 1, "bounces N", &Repl::cmd_bounces},
+    {"outfile", 1, 1, "outfile file.png", &Repl::cmd_outfile},
+    {"raytracer", 1, -1, "raytracer seq|naive-bvh|bbvh [indexed] [esc]|hip [indexed] [esc] [devices N|a,b,..]", &Repl::cmd_raytracer},
+    {"commit", 0, 0, "commit", &Repl::cmd_commit},
+    {"sppx", 1, 1, "sppx N", &Repl::cmd_sppx},
+    {"run", 0, 0, "run", &Repl::cmd_run},
+    {"rt_bench", 0, 0, "rt_bench", &Repl::cmd_run},
+    {"mesh", 1, 1, "mesh list", &Repl::cmd_mesh},
+    {"material", 1, -1, "material list|select name|albedo r g b|emissive r g b|roughness v|ior v|texture file.png|texture drop|brdf name|show", &Repl::cmd_material},
+    {"default-brdf", 1, 1, "default-brdf lambert|phong|layered-phong|gtr2|layered-gtr2", &Repl::cmd_default_brdf},
+    {"pointlight", 8, 9, "pointlight [replace] pos x y z col r g b", &Repl::cmd_pointlight},
+    {"omp", 1, 1, "omp on|off", &Repl::cmd_omp},
+    {"stats", 1, 1, "stats print|clear", &Repl::cmd_stats},
+    {"echo", 0, -1, "echo text", &Repl::cmd_echo},
+    {"history", 0, 0, "history", &Repl::cmd_history},
+    {"quit", 0, 0, "quit", &Repl::cmd_leave},
+    {"exit", 0, 0, "exit", &Repl::cmd_leave},
+    {"bvh", 1, -1, "bvh om|sm|sah N|triangles single|triangles multiple N|statistics|export depth file.obj", &Repl::cmd_backend},
+    {"hip", 1, -1, "hip reorder auto|on|off|sharding tiles|samples|tile N|seed N|jitter on|off", &Repl::cmd_backend},
+};
+
+void Repl::cmd_camera_vector(const Line &l) {
+	vec3 &v = l.word[0] == "at" ? scene.cam_pos : l.word[0] == "look" ? scene.cam_dir : scene.cam_up;
+	if (l.args() == 0) {  // a query
+		std::cout << v << std::endl;
+		return;
+	}
+	if (l.args() != 3) refuse("three numbers expected (x y z), or none to print the current value");
+	v = l.triple(0, l.word[0].c_str());
+	if (l.word[0] == "camup") camera_up_given = true;
+}
+
+// The scene's up axis is fixed once; until `camup` says otherwise the camera stands upright in it.
+void Repl::cmd_scene_up(const Line &l) {
+	if (l.args() == 0 && scene_up_given) {
+		std::cout << scene.up << std::endl;
+		return;
+	}
+	if (scene_up_given) refuse("the scene's up vector is already set (camup turns the camera)");
+	if (l.args() != 3) refuse("three numbers expected (x y z)");
+	scene.up = l.triple(0, "up");
+	scene_up_given = true;
+	if (!camera_up_given) scene.cam_up = scene.up, camera_up_given = true;
+}
+
+void Repl::cmd_load(const Line &l) {
+	const std::string problem = load_obj(scene, l.arg(0), l.arg(1));
+	if (!problem.empty()) refuse(problem);
+	scene_touched_at = line_no;
+}
+
+void Repl::cmd_resolution(const Line &l) {
+	const long w = l.integer(0, "width"), h = l.integer(1, "height");
+	if (w <= 0 || h <= 0 || w > 65536 || h > 65536) refuse("width and height must lie in 1..65536");
+	scene.w = (int)w, scene.h = (int)h;
+}
+
+void Repl::cmd_algo(const Line &l) {
+	static const struct {
+		const char *name;
+		int id;
+	} known[] = {{"primary", RTGI_ALGO_PRIMARY}, {"local", RTGI_ALGO_LOCAL}, {"path", RTGI_ALGO_PATH}};
+	for (const auto &k : known)
+		if (l.arg(0) == k.name) {
+			algo = k.id;
+			return;
+		}
+	refuse("no algorithm named '" + l.arg(0) + "' (primary, local, path)");
+}
+
+void Repl::cmd_bounces(const Line &l) {
+	const long n = l.integer(0, "bounces");
+	if (n < 0 || n > 64) refuse("bounces must lie in 0..64");
+	bounces = (unsigned)n;
+}
+
+void Repl::cmd_outfile(const Line &l) {
+	if (!opt.outfile_from_cmdline) opt.outfile = l.arg(0);  // -o on the command line wins over the script
+}
+
+// "devices 3" -> 0,1,2; "devices 0,2,5" -> as listed
+std::vector<int> device_list(const std::string &spec) {
+	std::vector<int> out;
+	long v;
+	if (spec.find(',') == std::string::npos) {
+		if (!whole_int(spec, v) || v < 1 || v > 64) refuse("devices: a count in 1..64 or a comma-separated list expected, got '" + spec + "'");
+		for (long d = 0; d < v; ++d) out.push_back((int)d);
+		return out;
+	}
+	std::istringstream parts(spec);
+	for (std::string p; std::getline(parts, p, ',');) {
+		if (!whole_int(p, v) || v < 0) refuse("devices: '" + p + "' is not a GPU number");
+		out.push_back((int)v);
+	}
+	if (out.empty() || out.size() > 64) refuse("devices: between 1 and 64 GPUs");
+	return out;
+}
+
+void Repl::cmd_raytracer(const Line &l) {
+	const std::string &kind = l.arg(0);
+	const bool own = kind == "hip", bbvh = kind == "bbvh";
+	bool indexed = false, esc = false;
+	std::vector<int> devices = {0};
+	if (kind == "seq" || kind == "naive-bvh") {
+		if (l.args() > 1) refuse("'" + kind + "' takes no options");
+		std::cout << "note: '" << kind << "' is served by the hip tracer (flat layout)" << std::endl;
+	} else if (own || bbvh) {
+		for (size_t k = 1; k < l.args(); ++k) {
+			const std::string &tag = l.arg(k);
+			if (tag == "indexed")
+				indexed = true;
+			else if (tag == "esc")
+				esc = true;
+			else if (own && tag == "devices" && k + 1 < l.args())
+				devices = device_list(l.arg(++k));
+			else if (own)
+				refuse("option '" + tag + "' not understood");
+			// (further words after `bbvh` are passed over, as the renderer's registry does)
+		}
+		if (esc && !indexed) refuse("early split clipping needs the indexed layout (raytracer " + kind + " indexed esc)");
+	} else
+		refuse("no ray tracer named '" + kind + "' (seq, naive-bvh, bbvh, hip)");
+	if (!opt.dry_run) {
+		rtgi_hip_renderer *fresh = rtgi_hip_renderer_create(devices.data(), (int)devices.size(), indexed ? RTGI_LAYOUT_INDEXED : RTGI_LAYOUT_FLAT, esc ? 1 : 0);
+		if (!fresh) refuse(rtgi_hip_renderer_last_error(nullptr));
+		if (renderer) rtgi_hip_renderer_destroy(renderer);
+		renderer = fresh;
+	}
+	tracer_desc = kind;
+	tracer_touched_at = line_no;
+}
+
+void Repl::cmd_commit(const Line &) {
+	if (scene.vertices.empty()) refuse("nothing loaded yet: there is no geometry to build a BVH over");
+	if (tracer_touched_at == 0) refuse("no ray tracer chosen yet (raytracer ...) to hand the scene to");
+	if (!opt.dry_run) {
+		const std::string problem = commit();
+		if (!problem.empty()) refuse(problem);
+	}
+	accel_touched_at = line_no;
+}
+
+void Repl::cmd_sppx(const Line &l) {
+	const long n = l.integer(0, "sppx");
+	if (n < 1 || n > (1 << 24)) refuse("sppx must be at least 1");
+	sppx = (unsigned)n;
+}
+
+// What must have happened, and in which order, before rays can be traced (the rules of driver/interaction.cpp:220-225):
+// a scene, a tracer, a commit later than both.
+void Repl::require_gpu_state(bool for_bench) const {
+	std::string lacking;
+	auto need = [&](bool have, const char *what) {
+		if (!have) lacking += (lacking.empty() ? "" : ", ") + std::string(what);
+	};
+	need(scene_touched_at != 0, "a scene (load)");
+	need(tracer_touched_at != 0, "a ray tracer (raytracer)");
+	need(accel_touched_at != 0, "a built BVH (commit)");
+	if (!for_bench) need(algo >= 0, "an algorithm (algo)");
+	if (!lacking.empty()) refuse("not ready, still missing: " + lacking);
+	if (accel_touched_at < tracer_touched_at) refuse("the ray tracer was chosen after the last commit: its BVH is stale, commit again");
+	if (accel_touched_at < scene_touched_at) refuse("the scene changed after the last commit: the BVH is stale, commit again");
+	if (!for_bench && algo != RTGI_ALGO_PRIMARY && !scene.have_light) refuse("this algorithm needs a light (pointlight pos x y z col r g b)");
+}
+
+void Repl::cmd_run(const Line &l) {
+	const bool bench = l.word[0] == "rt_bench";
+	require_gpu_state(bench);
+	if (opt.dry_run) return;
+	const std::string problem = bench ? rt_bench() : run();
+	if (!problem.empty()) refuse(problem);
+}
+
+void Repl::cmd_mesh(const Line &l) {
+	if (l.arg(0) != "list") refuse("only 'mesh list' is available");
+	for (const Object &o : scene.objects) std::cout << o.name << std::endl;
+}
+
+void Repl::cmd_material(const Line &l) {
+	const std::string &what = l.arg(0);
+	const size_t given = l.args() - 1;  // arguments after the sub-command
+	auto exactly = [&](size_t n, const char *form) {
+		if (given != n) refuse(std::string("expected: material ") + form);
+	};
+	if (what == "list") {
+		exactly(0, "list");
+		for (const Material &m : scene.materials) std::cout << m.name << std::endl;
+		return;
+	}
+	if (what == "select") {
+		exactly(1, "select name");
+		if (!material_named(l.arg(1))) refuse("no material named '" + l.arg(1) + "' (material list shows them)");
+		selected_material = l.arg(1);
+		return;
+	}
+	Material *m = selected_material.empty() ? nullptr : material_named(selected_material);
+	if (!m) refuse("select a material first (material select name)");
+	if (what == "albedo" || what == "emissive") {
+		exactly(3, "albedo|emissive r g b");
+		(what == "albedo" ? m->albedo : m->emissive) = l.triple(1, what.c_str());
+	} else if (what == "roughness" || what == "ior") {
+		exactly(1, "roughness|ior value");
+		(what == "ior" ? m->ior : m->roughness) = l.real(1, what.c_str());
+	} else if (what == "texture") {
+		exactly(1, "texture file.png | texture drop");
+		if (l.arg(1) == "drop")
+			m->texture = -1;  // (the image stays loaded: another material may show it)
+		else {
+			std::string problem;
+			const int t = load_image3f(scene.textures, l.arg(1), problem);
+			if (t < 0) refuse(problem);
+			m->texture = t, m->texture_path = l.arg(1);
+		}
+	} else if (what == "brdf") {
+		exactly(1, "brdf name|default");
+		const int k = l.arg(1) == "default" ? (int)scene.default_brdf : brdf_by_name(l.arg(1));
+		if (k < 0) refuse("no BRDF named '" + l.arg(1) + "'");
+		m->brdf = (uint32_t)k;
+	} else if (what == "show") {
+		exactly(0, "show");
+		std::cout << "albedo     " << m->albedo << "\nalbedo-tex " << (m->texture < 0 ? std::string("none") : scene.textures[(size_t)m->texture].path)
+		          << "\nemissive   " << m->emissive << "\nroughness  " << m->roughness << "\nior        " << m->ior << "\nbrdf       " << BRDF_NAMES[m->brdf]
+		          << std::endl;
+	} else
+		refuse("'" + what + "' is not a material sub-command");
+}
+
+void Repl::cmd_default_brdf(const Line &l) {
+	const int k = brdf_by_name(l.arg(0));
+	if (k < 0) refuse("no BRDF named '" + l.arg(0) + "'");
+	if (scene.default_brdf_set && !scene.materials.empty())
+		std::cout << "note: materials loaded so far keep the BRDF they were given" << std::endl;
+	scene.default_brdf = (uint32_t)k;  // what materials loaded from now on start with (libgi/scene.cpp:136)
+	scene.default_brdf_set = true;
+}
+
+void Repl::cmd_pointlight(const Line &l) {
+	const bool replace = l.arg(0) == "replace";
+	const size_t at = replace ? 1 : 0;
+	if (l.args() != at + 8 || l.arg(at) != "pos" || l.arg(at + 4) != "col") refuse("expected: pointlight [replace] pos x y z col r g b");
+	const vec3 pos = l.triple(at + 1, "pos"), col = l.triple(at + 5, "col");
+	// the renderer's algorithms light with the first point light only (gi/primary-hit.cpp:41)
+	if (scene.have_light && !replace) {
+		std::cout << "note: only the first point light is used (as by the reference's algorithms); use 'pointlight replace ...'" << std::endl;
+		return;
+	}
+	scene.light_pos = pos, scene.light_col = col, scene.have_light = true;
+}
+
+void Repl::cmd_omp(const Line &l) {
+	if (l.arg(0) != "on" && l.arg(0) != "off") refuse("expected: omp on|off");
+	// accepted for the scripts' sake: no host thread traces rays here
+}
+
+void Repl::cmd_stats(const Line &l) {
+	if (l.arg(0) == "clear")
+		timers.clear();
+	else if (l.arg(0) == "print")
+		print_timers();
+	else
+		refuse("expected: stats print|clear");
+}
+
+void Repl::cmd_echo(const Line &l) { std::cout << l.tail(0) << std::endl; }
+
+void Repl::cmd_history(const Line &) {
+	for (size_t k = 0; k + 1 < journal.size(); ++k) std::cout << journal[k] << std::endl;  // (all but this very line)
+}
+
+void Repl::cmd_leave(const Line &) { leave = true; }
+
+// `bvh ...` and `hip ...`: settings of the frame loop are kept here, everything else is the tracer's own business
+// (ray_tracer::interprete, the hook of driver/interaction.cpp:399-400).
+void Repl::cmd_backend(const Line &l) {
+	const std::string &what = l.arg(0), &value = l.arg(1);
+	if (l.word[0] == "hip" && (what == "sharding" || what == "tile" || what == "seed" || what == "jitter")) {
+		if (l.args() != 2) refuse("expected: hip " + what + " <value>");
+		if (what == "sharding") {
+			if (value != "tiles" && value != "samples") refuse("expected: hip sharding tiles|samples");
+			sharding = value == "tiles" ? RTGI_SHARD_TILES : RTGI_SHARD_SAMPLES;
+		} else if (what == "tile") {
+			const long n = l.integer(1, "tile");
+			if (n < 1 || n > 4096) refuse("tile edge must lie in 1..4096");
+			tile = (unsigned)n;
+		} else if (what == "seed")
+			seed = (unsigned)l.integer(1, "seed");
+		else {
+			if (value != "on" && value != "off") refuse("expected: hip jitter on|off");
+			jitter = value == "on";
+		}
+		return;
+	}
+	if (tracer_touched_at == 0) refuse("unknown command (no ray tracer yet that could take it)");
+	if (opt.dry_run) return;
+	const int rc = rtgi_hip_renderer_interprete(renderer, l.word[0].c_str(), l.tail(0).c_str());
+	if (rc < 0) refuse(rtgi_hip_renderer_last_error(renderer));
+	if (rc == 0) refuse("unknown command (the ray tracer does not know it either)");
+}
+
+void Repl::interpret(const std::string &text) {
+	const Line l(text);
+	if (l.word.empty() || l.word[0][0] == '#') return;  // blank line, comment
+	try {
+		const CommandEntry *entry = nullptr;
+		for (const CommandEntry &c : COMMANDS)
+			if (l.word[0] == c.name) entry = &c;
+		if (!entry) refuse("unknown command");
+		if ((int)l.args() < entry->least || (entry->most >= 0 && (int)l.args() > entry->most)) refuse(std::string("expected: ") + entry->usage);
+		(this->*entry->serve)(l);
+	} catch (const Refused &r) {
+		std::cerr << "line " << line_no << ": " << l.word[0] << ": " << r.why << std::endl;
+		++errors;
+	}
+}
+
+void Repl::read_commands(std::istream &input, bool prompt) {
+	std::string text;
+	while (!leave) {
+		if (prompt) std::cout << "rtgi > " << std::flush;
+		if (!std::getline(input, text)) break;
+		++line_no;
+		journal.push_back(text);
+		interpret(text);
+	}
+	if (prompt) std::cout << std::endl;
 }
 
 }  // namespace
@@ -915,9 +1015,9 @@ int run(int argc, char **argv) {
 			std::cerr << "cannot open " << repl.opt.script << std::endl;
 			return 2;
 		}
-		repl.loop(script, false);
+		repl.read_commands(script, false);
 	}
-	if (repl.opt.interact) repl.loop(std::cin, true);
-	for (auto &t : repl.timers) std::cout << t.first << ": " << t.second.first << " ms in " << t.second.second << " call(s)" << std::endl;
+	if (repl.opt.interact && !repl.leave) repl.read_commands(std::cin, true);
+	repl.print_timers();
 	return repl.opt.strict && repl.errors ? 1 : 0;
 }

@@ -21,7 +21,7 @@ SHARDING = {"tiles": 0, "samples": 1}
 # every symbol include/rtgi_hip_frame.h declares
 EXPORTS = [
     "rtgi_hip_renderer_create", "rtgi_hip_renderer_unique_id", "rtgi_hip_renderer_create_rank", "rtgi_hip_renderer_destroy", "rtgi_hip_renderer_device_count", "rtgi_hip_renderer_handle",
-    "rtgi_hip_renderer_interprete", "rtgi_hip_renderer_build", "rtgi_hip_renderer_set_materials", "rtgi_hip_renderer_set_textures", "rtgi_hip_renderer_render", "rtgi_hip_renderer_last_error",
+    "rtgi_hip_renderer_interprete", "rtgi_hip_renderer_build", "rtgi_hip_renderer_set_materials", "rtgi_hip_renderer_set_textures", "rtgi_hip_renderer_render", "rtgi_hip_renderer_rt_bench", "rtgi_hip_renderer_last_error",
 ]
 
 
@@ -67,6 +67,7 @@ def lib():
         L.rtgi_hip_renderer_set_materials.argtypes = [vp, vp, u32]
         L.rtgi_hip_renderer_set_textures.argtypes = [vp, vp, sz, u32, vp, sz, u32, vp, u32, vp, u32]
         L.rtgi_hip_renderer_render.argtypes = [vp, C.POINTER(Frame), vp, vp, C.POINTER(FrameStats)]
+        L.rtgi_hip_renderer_rt_bench.argtypes = [vp, C.POINTER(Frame), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
         L.rtgi_hip_renderer_last_error.argtypes = [vp]
         L.rtgi_hip_renderer_last_error.restype = cp
         _lib = L
@@ -128,6 +129,14 @@ class HipRenderer:
         rec["albedo"], rec["ior"], rec["roughness"] = albedo, ior, roughness
         rec["brdf"] = [tracer.BRDF[b] for b in brdf]
         self._check(lib().rtgi_hip_renderer_set_materials(self._r, rec.ctypes.data, len(rec)))
+
+    def rt_bench(self, cam_dir, cam_pos, cam_up, fovy, w, h):
+        """`rt_bench` (driver/main.cpp:50-65): closest_hit on one frame of camera rays -> (rays, ms)."""
+        f3 = C.c_float * 3
+        frame = Frame(Camera(f3(*cam_dir), f3(*cam_pos), f3(*cam_up), fovy, w, h), 1, 0, 0, f3(0, 0, 0), f3(1, 1, 1), 0, 0, 0, 0)
+        n, ms = C.c_uint64(0), C.c_double(0.0)
+        self._check(lib().rtgi_hip_renderer_rt_bench(self._r, C.byref(frame), C.byref(n), C.byref(ms)))
+        return n.value, ms.value
 
     def render(self, cam_dir, cam_pos, cam_up, fovy, w, h, sppx=1, algo="local", bounces=0, light_pos=(0, 0, 0),
                light_col=(1, 1, 1), seed=0, jitter=True, sharding="tiles", tile=0, want_rgb8=True):

@@ -25,7 +25,7 @@ LAYOUT = {"flat": 0, "indexed": 1}
 # every symbol include/rtgi_hip.h declares
 EXPORTS = [
     "rtgi_hip_device_count", "rtgi_hip_create", "rtgi_hip_destroy", "rtgi_hip_interprete", "rtgi_hip_build",
-    "rtgi_hip_upload_bvh", "rtgi_hip_num_nodes", "rtgi_hip_num_index", "rtgi_hip_root", "rtgi_hip_depth",
+    "rtgi_hip_build_shared", "rtgi_hip_device_of", "rtgi_hip_upload_bvh", "rtgi_hip_num_nodes", "rtgi_hip_num_index", "rtgi_hip_root", "rtgi_hip_depth",
     "rtgi_hip_incoherent_ray_cost",
     "rtgi_hip_get_nodes", "rtgi_hip_get_triangle_order", "rtgi_hip_closest_hit", "rtgi_hip_any_hit",
     "rtgi_hip_host_alloc", "rtgi_hip_host_free", "rtgi_hip_host_register", "rtgi_hip_host_unregister",
@@ -69,6 +69,8 @@ def lib():
         L.rtgi_hip_destroy.restype = None
         L.rtgi_hip_interprete.argtypes = [vp, cp, cp]
         L.rtgi_hip_build.argtypes = [vp, vp, sz, u32, vp, sz, u32]
+        L.rtgi_hip_build_shared.argtypes = [vp, u32, vp, sz, u32, vp, sz, u32]
+        L.rtgi_hip_device_of.argtypes = [vp]
         L.rtgi_hip_upload_bvh.argtypes = [vp, vp, u32, u32, vp, u32, vp, sz, u32, vp, sz, u32]
         for name in ("num_nodes", "num_index", "root", "depth"):
             f = getattr(L, "rtgi_hip_" + name)
@@ -170,6 +172,17 @@ class HipBvhTracer:
             raise ValueError("pos must be (nv, 3) float32 and tri (nt, 3) uint32")
         self._check(lib().rtgi_hip_build(self._h, pos.ctypes.data, 12, len(pos), tri.ctypes.data, 12, len(tri)))
         self.n_triangles = len(tri)
+
+    @staticmethod
+    def build_shared(tracers, pos, tri):
+        """build() for several tracers at once (one per GPU, created and configured alike): the tree is built and
+        flattened once and uploaded to each (rtgi_hip_build_shared)."""
+        pos = np.ascontiguousarray(pos, dtype=np.float32)
+        tri = np.ascontiguousarray(tri, dtype=np.uint32)
+        handles = (C.c_void_p * len(tracers))(*[t._h for t in tracers])
+        tracers[0]._check(lib().rtgi_hip_build_shared(handles, len(tracers), pos.ctypes.data, 12, len(pos), tri.ctypes.data, 12, len(tri)))
+        for t in tracers:
+            t.n_triangles = len(tri)
 
     def upload_bvh(self, nodes, root, index, pos, tri):
         nodes = np.ascontiguousarray(nodes, dtype=NODE56_DTYPE)

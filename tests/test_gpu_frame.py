@@ -182,3 +182,70 @@ def test_frame_argument_checks():
     with pytest.raises(tracer.RtgiHipError):
         r.render(fovy=65.0, w=8, h=8, sppx=0, **CAM)
     assert r.interprete("bvh", "sah 8") and not r.interprete("whatever")
+
+
+def test_a_failing_part_is_an_error_not_a_hang(monkeypatch):
+    """One part of several fails while the others render: render() returns the error (no part enters the framebuffer
+    exchange), and the renderer goes on working afterwards."""
+    from raytracing_amd import tracer
+    s = _scene()
+    kw = dict(fovy=65.0, w=96, h=64, sppx=1, algo="local", light_pos=LIGHT_POS, light_col=LIGHT_COL, seed=1, **CAM)
+    r = _renderer(s, devices=(0, 0))
+    good, _, _ = r.render(**kw)
+    monkeypatch.setenv("RTGI_HIP_FAIL_PART", "1")
+    with pytest.raises(tracer.RtgiHipError, match="part 1.*injected"):
+        r.render(**kw)
+    monkeypatch.delenv("RTGI_HIP_FAIL_PART")
+    again, _, _ = r.render(**kw)
+    assert np.array_equal(again.view(np.uint32), good.view(np.uint32))
+
+
+def test_a_failing_rank_takes_part_in_the_status_exchange(monkeypatch):
+    """One process per GPU (here a world of one rank, through RCCL): a rank whose part fails still enters the one-word
+    status all-reduce, returns its own error, and the communicator survives for the next frame."""
+    from raytracing_amd import tracer
+    s = _scene()
+    kw = dict(fovy=65.0, w=96, h=64, sppx=1, algo="local", light_pos=LIGHT_POS, light_col=LIGHT_COL, seed=1, **CAM)
+    r = frame.HipRenderer(devices=(0,), rank=0, world=1, unique_id=frame.HipRenderer.unique_id())
+    r.build(s["pos"], s["normals"], s["tri"], s["material_id"], s["albedo"])
+    good, _, st = r.render(**kw)
+    assert st["used_rccl"] == 1
+    monkeypatch.setenv("RTGI_HIP_FAIL_PART", "0")
+    with pytest.raises(tracer.RtgiHipError, match="injected"):
+        r.render(**kw)
+    monkeypatch.delenv("RTGI_HIP_FAIL_PART")
+    again, _, st = r.render(**kw)
+    assert st["used_rccl"] == 1 and np.array_equal(again.view(np.uint32), good.view(np.uint32))
+
+
+def test_shared_build_gives_every_handle_the_tree_of_a_single_build():
+    """rtgi_hip_build_shared (what `commit` does for `devices N`): one host build, every handle ends up with the nodes,
+    the triangle order and the hits of a handle built on its own."""
+    from raytracing_amd import tracer
+    pos, tri, _ = scenes.soup(30000, seed=3)
+    rays = scenes.random_rays(20000, seed=4)
+    alone = tracer.HipBvhTracer(layout="indexed")
+    alone.interprete("bvh", "sah 8")
+    alone.build(pos, tri)
+    want = alone.closest_hit(rays)
+    group = [tracer.HipBvhTracer(layout="indexed") for _ in range(3)]
+    for t in group:
+        t.interprete("bvh", "sah 8")
+    tracer.HipBvhTracer.build_shared(group, pos, tri)
+    for t in group:
+        assert t.nodes().tobytes() == alone.nodes().tobytes()
+        assert np.array_equal(t.triangle_order(), alone.triangle_order())
+        assert t.incoherent_ray_cost == alone.incoherent_ray_cost
+        assert t.closest_hit(rays).tobytes() == want.tobytes()
+    group[1].interprete("bvh", "om")
+    with pytest.raises(tracer.RtgiHipError, match="same layout and bvh settings"):
+        tracer.HipBvhTracer.build_shared(group, pos, tri)
+
+
+def test_rt_bench_leaves_the_callers_device_alone():
+    import torch
+    s = _scene()
+    r = _renderer(s)
+    n, ms = r.rt_bench(fovy=65.0, w=320, h=200, **CAM)
+    assert n == 320 * 200 and ms > 0.0
+    assert torch.cuda.current_device() == 0

@@ -75,29 +75,38 @@ def test_every_command_parses(tmp_path):
 
 
 @pytest.mark.parametrize("script,message", [
-    ("at 1 2\n", "requires 3 numerical components"),
-    ("up 0 1 0\nup 0 0 1\n", "Cannot set scene up vector twice"),
+    ("at 1 2\n", "three numbers expected"),
+    ("at 1 2 x\n", "'x' is not a number"),
+    ("up 0 1 0\nup 0 0 1\n", "up vector is already set"),
     ("load no-such-file.obj\n", "Failed to load file"),
-    ("algo radiosity\n", "There is no gi algorithm called 'radiosity'"),
-    ("raytracer embree\n", "There is no ray tracer called 'embree'"),
-    ("raytracer bbvh esc\n", "This combination is technically problematic"),
-    ("commit\n", "There is no scene data to work with"),
-    ("load render-data/tri.obj\ncommit\n", "There is no ray traversal scheme"),
-    ("load render-data/tri.obj\nraytracer hip\ncommit\nrun\n", "prior to running"),
-    ("load render-data/tri.obj\nraytracer hip\ncommit\nraytracer hip indexed\nalgo primary\nrun\n", "up-to-date acceleration structure"),
-    ("raytracer hip\nload render-data/tri.obj\ncommit\nload render-data/2tri.obj\nalgo primary\nrun\n", "out-dated"),
-    ("load render-data/tri.obj\nraytracer hip\ncommit\nalgo local\nrun\n", "There is no light"),
-    ("material roughness 0.5\n", "No material selected"),
-    ("load render-data/tri.obj\nmaterial select nothing\n", "No material called 'nothing'"),
-    ("default-brdf velvet\n", "No such brdf defined: velvet"),
+    ("algo radiosity\n", "no algorithm named 'radiosity'"),
+    ("raytracer embree\n", "no ray tracer named 'embree'"),
+    ("raytracer bbvh esc\n", "early split clipping needs the indexed layout"),
+    ("raytracer hip devices 0\n", "devices: a count in 1..64"),
+    ("raytracer hip fast\n", "option 'fast' not understood"),
+    ("commit\n", "nothing loaded yet"),
+    ("load render-data/tri.obj\ncommit\n", "no ray tracer chosen yet"),
+    ("load render-data/tri.obj\nraytracer hip\ncommit\nrun\n", "still missing: an algorithm (algo)"),
+    ("run\n", "still missing: a scene (load), a ray tracer (raytracer), a built BVH (commit), an algorithm (algo)"),
+    ("load render-data/tri.obj\nraytracer hip\ncommit\nraytracer hip indexed\nalgo primary\nrun\n", "chosen after the last commit"),
+    ("raytracer hip\nload render-data/tri.obj\ncommit\nload render-data/2tri.obj\nalgo primary\nrun\n", "scene changed after the last commit"),
+    ("load render-data/tri.obj\nraytracer hip\ncommit\nalgo local\nrun\n", "needs a light"),
+    ("material roughness 0.5\n", "select a material first"),
+    ("load render-data/tri.obj\nmaterial select nothing\n", "no material named 'nothing'"),
+    ("load render-data/tri.obj\nmaterial select tri\nmaterial albedo 1 2\n", "expected: material albedo|emissive r g b"),
+    ("load render-data/tri.obj\nmaterial select tri\nmaterial shine 1\n", "'shine' is not a material sub-command"),
+    ("default-brdf velvet\n", "no BRDF named 'velvet'"),
     ("load render-data/tri.obj\nmaterial select tri\nmaterial texture no-such.png\n", "cannot open no-such.png"),
     ("load render-data/tri.obj\nmaterial select tri\nmaterial texture render-data/tri.obj\n", "is not a PNG file"),
-    ("pointlight at 1 2 3\n", "poinlight [replace] pos x y z col x y z"),
-    ("sppx many\n", "positive integral value"),
-    ("resolution 640\n", "requires 2 integral values"),
-    ("stats reset\n", "No such stats subcommand"),
-    ("frobnicate\n", "Unknown command"),
-    ("bvh sah 16\n", "Unknown command"),  # no tracer yet to take it
+    ("pointlight at 1 2 3\n", "expected: pointlight [replace] pos x y z col r g b"),
+    ("pointlight pos 1 2 3 colour 1 1 1\n", "expected: pointlight [replace] pos x y z col r g b"),
+    ("sppx many\n", "'many' is not a whole number"),
+    ("sppx 0\n", "sppx must be at least 1"),
+    ("resolution 640\n", "expected: resolution width height"),
+    ("stats reset\n", "expected: stats print|clear"),
+    ("hip tile 0\n", "tile edge must lie in 1..4096"),
+    ("frobnicate\n", "unknown command"),
+    ("bvh sah 16\n", "unknown command"),  # no tracer yet to take it
 ])
 def test_refusals(script, message, tmp_path):
     r = _run(script, tmp_path)
@@ -105,9 +114,16 @@ def test_refusals(script, message, tmp_path):
     assert message in r.stderr, r.stderr
 
 
+def test_quit_ends_the_script_and_history_lists_the_lines_before(tmp_path):
+    r = _run("echo one\n# a comment\n\nhistory\nquit\necho never\n", tmp_path)
+    assert r.returncode == 0, r.stderr
+    assert "never" not in r.stdout
+    assert r.stdout.count("echo one") == 1 and "# a comment" in r.stdout
+
+
 def test_errors_do_not_stop_the_script(tmp_path):
     r = _run("frobnicate\necho still here\n", tmp_path)
-    assert "still here" in r.stdout and "command 1 (frobnicate): Unknown command" in r.stderr
+    assert "still here" in r.stdout and "line 1: frobnicate: unknown command" in r.stderr
 
 
 @pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="the reference tree is only present in the build container")
