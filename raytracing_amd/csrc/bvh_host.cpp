@@ -729,9 +729,12 @@ void flatten_tree(const HostTree &t, const SceneView &scene, int layout, FlatTre
 	// Inner nodes are renumbered level by level (breadth first): the upper levels, which every ray visits,
 	// become one contiguous block (the kernel keeps the first ones in LDS), and two inner siblings share one
 	// aligned 128-byte line, so that fetching the nearer child brings in the one that waits on the stack.
+	// n_inner counts record slots (the numbering leaves a few empty), not nodes.
 	// RTGI_HIP_NODE_ORDER=dfs keeps the reference's pre-order, =bfs numbers without the alignment gaps.
 	std::vector<int32_t> inner_id(n, -1);
 	uint32_t n_inner = 0;
+	out.implicit_limit = 0;
+	out.heap_levels = 0;
 	const char *order_env = getenv("RTGI_HIP_NODE_ORDER");
 	if (order_env && std::string(order_env) == "dfs") {
 		for (uint32_t i = 0; i < n; ++i)
@@ -739,11 +742,40 @@ void flatten_tree(const HostTree &t, const SceneView &scene, int layout, FlatTre
 	} else if (!(order_env && std::string(order_env) == "bfs")) {
 		std::vector<uint32_t> queue;
 		queue.reserve(n);
+		size_t head = 0;
 		if (t.nodes[t.root].link_r >= 0) {
+			// The levels at the top of the tree in which every node is an inner node are numbered like a heap, the root
+			// as 1: the children of node i are 2i and 2i + 1, which the kernel computes instead of fetching the links.
+			// (Median splits give such levels down to the last one or two; any other tree has a few.) Slot 0 stays empty.
 			queue.push_back(t.root);
-			inner_id[t.root] = (int32_t)n_inner++;
+			inner_id[t.root] = 1;
+			n_inner = 2;
+			size_t level_size = 1;
+			uint32_t levels = 1;  // levels numbered so far
+			for (;;) {
+				bool all_inner = levels < 24;  // (ids stay far below the 2^25 nodes a buffer descriptor can address)
+				for (size_t k = head; k < head + level_size && all_inner; ++k) {
+					const rtgi_node56 &nd = t.nodes[queue[k]];
+					all_inner = t.nodes[nd.link_l].link_r >= 0 && t.nodes[nd.link_r].link_r >= 0;
+				}
+				if (!all_inner) break;
+				for (size_t k = head; k < head + level_size; ++k) {
+					const rtgi_node56 &nd = t.nodes[queue[k]];
+					const int32_t id = inner_id[queue[k]];
+					inner_id[nd.link_l] = 2 * id, inner_id[nd.link_r] = 2 * id + 1;
+					queue.push_back((uint32_t)nd.link_l), queue.push_back((uint32_t)nd.link_r);
+				}
+				head += level_size;
+				level_size *= 2;
+				++levels;
+				n_inner = 1u << levels;
+			}
+			// nodes of levels 0 .. levels - 2 have their children among the heap-numbered ones
+			out.implicit_limit = levels >= 2 ? 1u << (levels - 1) : 0u;
+			out.heap_levels = levels >= 2 ? levels : 0u;
 		}
-		for (size_t head = 0; head < queue.size(); ++head) {
+		// the rest level by level; two inner siblings share one aligned 128-byte line
+		for (; head < queue.size(); ++head) {
 			const rtgi_node56 &nd = t.nodes[queue[head]];
 			const bool li = t.nodes[nd.link_l].link_r >= 0, ri = t.nodes[nd.link_r].link_r >= 0;
 			if (li && ri && (n_inner & 1u)) ++n_inner;

@@ -42,6 +42,8 @@ struct HostTree {
 //   [0] = l.min.x r.min.x l.min.y r.min.y    [1] = l.min.z r.min.z l.max.x r.max.x
 //   [2] = l.max.y r.max.y l.max.z r.max.z    [3] = bits(link_l) bits(link_r) 0 0
 // A link >= 0 is an inner-node index; a link < 0 is ~slot of the first triangle of a leaf.
+// Nodes with an index below implicit_limit are numbered like a heap (root 1, children of i: 2i and 2i + 1, all of
+// them inner nodes): their links are stored like all others, but a reader need not fetch them.
 // Triangles, 48 bytes each as three float4, in leaf order:
 //   [0] = A.xyz, bits(id reported in rtgi_hit.ref)
 //   [1] = (A - B).xyz, bits(1 if last triangle of its leaf else 0)
@@ -51,7 +53,9 @@ struct FlatTree {
 	std::vector<float> tris;   // 12 floats per slot
 	std::vector<float> corners;  // 12 floats (A, B, C as float4) per id that a hit can report
 	int32_t root_ref = 0;
-	uint32_t n_inner = 0, n_slots = 0;
+	uint32_t n_inner = 0, n_slots = 0;  // n_inner: record slots in `nodes` (a few stay empty)
+	uint32_t implicit_limit = 0;
+	uint32_t heap_levels = 0;  // levels 0 .. heap_levels - 1 are heap-numbered (0 or >= 2); implicit_limit = 2^(heap_levels - 1)
 	uint32_t depth = 0;
 };
 

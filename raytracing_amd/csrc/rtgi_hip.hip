@@ -194,11 +194,11 @@ struct rtgi_hip_tracer {
 	float reorder_min_pops = 120.0f;
 	std::vector<rtgi_ray> probe_rays;
 	uint32_t node_bytes = 0, tri_bytes = 0;
-	int refill_min = 24, leaf_min = 12, drain_leaf_min = 4;
+	int refill_min = 24, leaf_min = 12, drain_leaf_min = 4, link_min = 4;
 	bool top_in_lds = true;
 	uint32_t blocks_per_cu = 1;
 	// division of a workgroup's LDS (set at upload from the tree's depth and size, see trace_kernel.h)
-	uint32_t stack_levels = 1, top_nodes = 0, lds_bytes = 0;
+	uint32_t stack_levels = 1, top_nodes = 0, lds_bytes = 0, implicit_limit = 0;
 	int force_stack_levels = 0, max_top_nodes = 1 << 30;
 	uint32_t n_segments = 8;
 	int32_t *d_spill = nullptr;
@@ -287,6 +287,7 @@ void read_tunables(rtgi_hip_tracer *h) {
 	h->refill_min = number("RTGI_HIP_REFILL_MIN", 1, 64, h->refill_min);
 	h->leaf_min = number("RTGI_HIP_LEAF_MIN", 1, 64, h->leaf_min);
 	h->drain_leaf_min = number("RTGI_HIP_DRAIN_LEAF_MIN", 1, 64, h->drain_leaf_min);
+	h->link_min = number("RTGI_HIP_LINK_MIN", 1, 64, h->link_min);
 	h->n_segments = number("RTGI_HIP_SEGMENTS", 1, 8, 8) == 1 ? 1u : 8u;
 	h->top_in_lds = number("RTGI_HIP_TOP_IN_LDS", 0, 1, 1) != 0;
 	h->force_stack_levels = number("RTGI_HIP_STACK_LEVELS", 0, 64, 0);
@@ -316,14 +317,25 @@ int upload_flat(rtgi_hip_tracer *h, const rtgi::FlatTree &flat, const rtgi::Scen
 	// (what one workgroup may ask for: the opt-in limit where the runtime reports one, else the 64 KiB every GPU grants)
 	const uint32_t lds_block = prop.sharedMemPerBlockOptin >= 65536 ? (uint32_t)prop.sharedMemPerBlockOptin : 65536u;
 	const uint32_t lds_budget = std::min<uint32_t>({lds_cu / h->blocks_per_cu, lds_block, 160u << 10});
-	h->stack_levels = flat.depth <= (uint32_t)rtgi_dev::MAX_STACK_LDS ? std::max<uint32_t>(flat.depth, 1) : (uint32_t)rtgi_dev::DEEP_STACK_LDS;
+	// (Nodes of the heap-numbered levels at the top of the tree wait as bits in a register: only the inner levels from
+	// the last heap-numbered one down push into memory, one entry each at most.)
+	const bool implicit_links = !getenv("RTGI_HIP_NO_IMPLICIT_LINKS") && flat.heap_levels >= 2;
+	const uint32_t stack_need = std::max<uint32_t>(implicit_links && rtgi_dev::TRAIL ? flat.depth - (flat.heap_levels - 1) : flat.depth, 1);
+	h->stack_levels = stack_need <= (uint32_t)rtgi_dev::MAX_STACK_LDS ? stack_need : (uint32_t)rtgi_dev::DEEP_STACK_LDS;
 	if (h->force_stack_levels) h->stack_levels = (uint32_t)h->force_stack_levels;
 	while (h->stack_levels > 1 && (size_t)h->stack_levels * BLOCK * sizeof(int32_t) > lds_budget) --h->stack_levels;
-	h->spill_levels = flat.depth > h->stack_levels ? flat.depth - h->stack_levels : 0;
+	h->spill_levels = stack_need > h->stack_levels ? stack_need - h->stack_levels : 0;
 	const size_t stack_bytes = (size_t)h->stack_levels * BLOCK * sizeof(int32_t);
 	if (stack_bytes > lds_budget) return fail(h, RTGI_ERR_DEVICE, "this GPU's LDS does not hold one stack slot per lane");
-	h->top_nodes = h->top_in_lds ? (uint32_t)std::min<size_t>({(lds_budget - stack_bytes) / 64, (size_t)flat.n_inner, (size_t)h->max_top_nodes}) : 0;
-	h->lds_bytes = (uint32_t)(stack_bytes + (size_t)h->top_nodes * 64);
+	// the copy of the top of the tree: 48 bytes per node, 8 more for each copied node whose links must be read
+	h->implicit_limit = implicit_links ? flat.implicit_limit : 0u;
+	{
+		const size_t left = lds_budget - stack_bytes;
+		size_t fit = left / 48;
+		if (fit > h->implicit_limit) fit = h->implicit_limit + (left - (size_t)h->implicit_limit * 48) / 56;
+		h->top_nodes = h->top_in_lds ? (uint32_t)std::min<size_t>({fit, (size_t)flat.n_inner, (size_t)h->max_top_nodes}) : 0;
+	}
+	h->lds_bytes = (uint32_t)rtgi_dev::lds_bytes_for(h->stack_levels, h->top_nodes, h->implicit_limit);
 	// buffer descriptors address the arrays with 32-bit byte offsets
 	if (flat.n_inner >= (1u << 25) || flat.n_slots >= 44000000u)
 		return fail(h, RTGI_ERR_INVALID, "scene too large: at most 2^25 inner nodes and 44M leaf slots");
@@ -648,7 +660,9 @@ int launch_batches(rtgi_hip_tracer *h, const BatchView *given, uint32_t n_given,
 	a.refill_min = h->refill_min;
 	a.leaf_min = h->leaf_min;
 	a.drain_leaf_min = h->drain_leaf_min;
+	a.link_min = h->implicit_limit ? h->link_min : 1;  // (a tree without heap-numbered levels: every inner node has links)
 	a.top_nodes = (int32_t)h->top_nodes;
+	a.implicit_limit = (int32_t)h->implicit_limit;
 	a.stack_levels = (int32_t)h->stack_levels;
 	// (a small batch still spreads over the CUs: a workgroup per 256 rays, its other waves find the supply dry at once)
 	uint32_t blocks = (n + 255) / 256;

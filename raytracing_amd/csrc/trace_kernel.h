@@ -15,11 +15,15 @@
 //    subtracts / multiplies for both children;
 //  * loads go through buffer descriptors: a 32-bit per-lane offset instead of 64-bit address arithmetic,
 //    and an out-of-range index reads zeros instead of faulting;
-//  * the pending-node stack keeps its top in a register and the rest in LDS as [level][lane] (any mix of
-//    depths is conflict-free); trees deeper than MAX_STACK_LDS use the DEEP variant, which continues the stack
-//    in a global area sized from the tree depth, so the stack cannot overflow;
+//  * the pending-node stack keeps its top in a register; pending nodes of the heap-numbered levels are one bit
+//    each in a register (see below), the rest lives in LDS as [level][lane] (any mix of depths is conflict-free);
+//    trees with more than MAX_STACK_LDS levels below the heap-numbered ones use the DEEP variant, which continues
+//    the stack in a global area sized from the tree depth, so the stack cannot overflow;
 //  * the first nodes of the breadth-first numbering, which every ray visits, are read from a copy in LDS (as
 //    many as fit beside the stacks);
+//  * the levels at the top of the tree that consist of inner nodes only are numbered like a heap, so the children of
+//    node i are 2i and 2i + 1 and a visit fetches the twelve box planes (three 16-byte loads) but no links; median
+//    splits give such levels down to the last one or two;
 //  * large batches are traced through a permutation (octant, length class, Morton code of the origin), each XCD
 //    starting on the rays of one direction octant, the long rays first.
 #pragma once
@@ -40,6 +44,14 @@ namespace rtgi_dev {
 #define RTGI_BLOCK 1024
 #endif
 constexpr int BLOCK = RTGI_BLOCK;  // threads per workgroup
+#ifndef RTGI_WAVES_PER_SIMD
+#define RTGI_WAVES_PER_SIMD (RTGI_BLOCK / 256)
+#endif
+constexpr int WAVES_PER_SIMD = RTGI_WAVES_PER_SIMD;  // resident waves per SIMD the register budget is kept within (all workgroups of a CU together)
+#ifndef RTGI_TRAIL
+#define RTGI_TRAIL 0  // 1: pending nodes of the heap-numbered levels are bits in a register instead of stack entries
+#endif
+constexpr bool TRAIL = RTGI_TRAIL;
 constexpr int MAX_STACK_LDS = 24;  // at most this many pending nodes per lane in LDS (beyond the one in a register)
 constexpr int DEEP_STACK_LDS = 20; // trees deeper than MAX_STACK_LDS: this many in LDS, the rest in the global spill area
 constexpr int COUNTER_STRIDE = 32;
@@ -78,7 +90,9 @@ struct TraceArgs {
 	void *batch_out[MAX_BATCHES];       // float4 per ray (closest_hit) or one byte per ray (any_hit)
 	uint32_t batch_any;                 // bit b: batch b is an any_hit batch
 	int32_t top_nodes;      // visits to inner nodes 0 .. top_nodes-1 are served from a copy in LDS
-	int32_t stack_levels;   // pending-node slots per lane in LDS; dynamic LDS = stack_levels * BLOCK * 4 + top_nodes * 64 bytes
+	int32_t stack_levels;   // pending-node slots per lane in LDS; dynamic LDS: see lds_bytes_for()
+	int32_t implicit_limit; // inner nodes below this index are numbered like a heap: children 2i and 2i + 1, no link fetch
+	int32_t link_min;       // lanes on other inner nodes take their step once this many have gathered
 #ifdef RTGI_DIAG
 	unsigned long long *diag;  // diagnostic build only: 8 counters summed over all waves
 #endif
@@ -115,14 +129,26 @@ __device__ __forceinline__ float next_up(float x) {
 	return __uint_as_float((b & 0x80000000u) ? b - 1u : b + 1u);
 }
 
+// Dynamic LDS of a workgroup: the stacks, then a copy of the first top_nodes node records without their links
+// (48 bytes each, node after node: lanes on different nodes then start in 16 different bank groups, as conflict-free
+// as four separate arrays, and one address serves the three reads), then the links (8 bytes) of those copied nodes
+// that are not heap-numbered.
+__host__ __device__ inline size_t lds_bytes_for(uint32_t stack_levels, uint32_t top_nodes, uint32_t implicit_limit) {
+	return (size_t)stack_levels * BLOCK * sizeof(int32_t) + (size_t)top_nodes * 48 + (top_nodes > implicit_limit ? (size_t)(top_nodes - implicit_limit) * 8 : 0);
+}
+
 // MODE 0: closest_hit, 1: any_hit, 2: a launch over several batches, each of one kind or the other.
 template <int MODE, bool COUNT, bool DEEP>
+#ifdef RTGI_PLAIN_BOUNDS
 __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
+#else
+__global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void trace_kernel(TraceArgs a) {
+#endif
 	constexpr bool MIXED = MODE == 2;
 	extern __shared__ __align__(16) unsigned char s_mem[];
 	const int32_t stack_levels = a.stack_levels;
 	int32_t *const s_stack = reinterpret_cast<int32_t *>(s_mem);  // [level][thread]: bank = lane, conflict-free for any mix of depths
-	u32x4 *const s_top = reinterpret_cast<u32x4 *>(s_mem + (size_t)stack_levels * BLOCK * sizeof(int32_t));  // [quad][node]: lanes on different nodes read different 16-byte slots
+	u32x4 *const s_top = reinterpret_cast<u32x4 *>(s_mem + (size_t)stack_levels * BLOCK * sizeof(int32_t));  // [node][3]
 	const int tid = threadIdx.x;
 	const int lane = tid & 63;
 	const uint32_t gl = blockIdx.x * BLOCK + tid;
@@ -134,9 +160,17 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 	// Every ray walks the top of the tree; a copy in LDS takes those visits off the vector cache, whose access
 	// rate is what the kernel runs against. (Reads beyond the node array return zeros.)
 	const int32_t top_nodes = a.top_nodes;
+	const int32_t implicit_limit = a.implicit_limit;
+	u32x2 *const s_links = reinterpret_cast<u32x2 *>(s_top + 3 * top_nodes);  // [node - implicit_limit], nodes of the copy only
+	const uint32_t top_offset = (uint32_t)stack_levels * BLOCK * sizeof(int32_t);
+	const uint32_t heap_end = 2u * (uint32_t)implicit_limit;  // heap-numbered nodes have indices below this
 	if (top_nodes) {
-		for (int i = tid; i < 4 * top_nodes; i += BLOCK)
-			s_top[(i & 3) * top_nodes + (i >> 2)] = __builtin_amdgcn_raw_buffer_load_b128(node_rsrc, i << 4, 0, 0);
+		for (int i = tid; i < 3 * top_nodes; i += BLOCK) {
+			const int node = i / 3, quad = i - 3 * node;
+			s_top[i] = __builtin_amdgcn_raw_buffer_load_b128(node_rsrc, (node << 6) + (quad << 4), 0, 0);
+		}
+		for (int i = implicit_limit + tid; i < top_nodes; i += BLOCK)
+			s_links[i - implicit_limit] = __builtin_amdgcn_raw_buffer_load_b64(node_rsrc, (i << 6) + 48, 0, 0);
 		__syncthreads();
 	}
 
@@ -153,6 +187,11 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 	unsigned long long sum_rays = 0, sum_inner = 0, sum_tri = 0, sum_top = 0;  // COUNT: over all rays of this lane
 	int32_t cur = IDLE;
 	int sp = 0;          // pending entries in memory (the next node to visit is `cur`, in a register)
+	// Pending nodes inside the heap-numbered levels need no memory: the sibling of heap node i is i ^ 1 and its
+	// parent i >> 1, so one bit per level says whether the sibling of the path's node on that level still waits.
+	// anchor = the deepest heap-numbered node on the current path; bit j of trail belongs to anchor >> j. Everything
+	// pushed below the heap levels lies deeper than any of these, so the stack in memory is emptied first.
+	uint32_t anchor = 0, trail = 0;
 	bool plain = true;   // no NaN can arise in this ray's slab tests
 	bool more = true;    // wave-uniform: some segment may still have rays
 	// Each XCD has its own L2. Waves of one XCD draw rays from the same contiguous part of the batch, so that
@@ -190,11 +229,16 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 		}
 		cur = IDLE;
 	};
-	auto advance = [&]() {  // next pending node, or the ray is done
-		if (sp == 0)
-			finish();
-		else
+	auto advance = [&]() {  // next pending node (the deepest one), or the ray is done
+		if (sp != 0)
 			cur = pop();
+		else if (TRAIL && trail != 0) {
+			const int up = __builtin_ctz(trail);
+			anchor = (anchor >> up) ^ 1u;
+			trail = (trail >> up) ^ 1u;
+			cur = (int32_t)anchor;
+		} else
+			finish();
 	};
 
 #ifdef RTGI_DIAG
@@ -264,6 +308,7 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 				n_inner = n_tri = n_top = 0;
 				cur = a.root_ref;
 				sp = 0;
+				anchor = (uint32_t)a.root_ref, trail = 0;
 				lim = any_lane ? lim0 : __builtin_fminf(best_t, lim0);
 			}
 		}
@@ -273,89 +318,117 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
 			continue;
 		}
 		const bool wave_plain = __ballot(cur != IDLE && !plain) == 0;
-		// While rays are in supply, lanes that reached a leaf wait for company (the triangle code is long); once the
-		// supply is dry the launch ends with its slowest ray, so nobody waits any more.
-		const int keep_going = max(0, (int)__popcll(busy) - (more ? a.leaf_min : a.drain_leaf_min));
+		// While rays are in supply, lanes that are through with a phase wait for company (each phase is a long piece of
+		// code, run for however many lanes need it); once the supply is dry the launch ends with its slowest ray, so
+		// they wait for fewer. A phase runs once at least if it has a lane, and goes on until `leave` of the lanes that
+		// were busy when it began stand outside it.
+		const int n_busy = (int)__popcll(busy);
+		const int leave = __builtin_amdgcn_readfirstlane(more ? a.leaf_min : a.drain_leaf_min);
+		const int link_min = __builtin_amdgcn_readfirstlane(more ? a.link_min : 1);
 
-		// ---- inner nodes: every lane standing on an inner node takes one step per iteration; the loop ends
-		// once leaf_min lanes have left it (reached a leaf or finished their ray), or nobody is left --------
-		auto inner_phase = [&](auto plain_tag) {
+		// one step of one lane: the two child boxes of its node against its ray; which ones to enter, and which one first
+		auto boxes = [&](auto plain_tag, const u32x4 q0, const u32x4 q1, const u32x4 q2, bool &hl, bool &hr, bool &left_first) {
 			constexpr bool PLAIN = decltype(plain_tag)::value;
-			// one step of one lane: the two child boxes of its node against its ray, then down, or on to a pending node
-			auto step = [&](const u32x4 q0, const u32x4 q1, const u32x4 q2, const int32_t link_l, const int32_t link_r) {
-				if (COUNT) ++n_inner;
-				auto pair = [](uint32_t u, uint32_t v) { return f32x2{__uint_as_float(u), __uint_as_float(v)}; };
-				// .x = left child, .y = right child; (box - o) * id as in libgi/intersect.h:210-221
-				const f32x2 ax = (pair(q0.x, q0.y) - f32x2{ox, ox}) * f32x2{ix, ix};
-				const f32x2 ay = (pair(q0.z, q0.w) - f32x2{oy, oy}) * f32x2{iy, iy};
-				const f32x2 az = (pair(q1.x, q1.y) - f32x2{oz, oz}) * f32x2{iz, iz};
-				const f32x2 bx = (pair(q1.z, q1.w) - f32x2{ox, ox}) * f32x2{ix, ix};
-				const f32x2 by = (pair(q2.x, q2.y) - f32x2{oy, oy}) * f32x2{iy, iy};
-				const f32x2 bz = (pair(q2.z, q2.w) - f32x2{oz, oz}) * f32x2{iz, iz};
-				float dl, dr;
-				bool hl, hr;
-				if (PLAIN) {
-					// no NaN possible: the selects of intersect.h:212-228 are exact min / max, and
-					// !(t1 > t2) && !(t2 < t_min) && !(t1 > t_max) [&& t1 < closest t] folds into two compares
-					dl = vmax3(vmin(ax.x, bx.x), vmin(ay.x, by.x), vmin(az.x, bz.x));
-					dr = vmax3(vmin(ax.y, bx.y), vmin(ay.y, by.y), vmin(az.y, bz.y));
-					const float fl = vmin3(vmax(ax.x, bx.x), vmax(ay.x, by.x), vmax(az.x, bz.x));
-					const float fr = vmin3(vmax(ax.y, bx.y), vmax(ay.y, by.y), vmax(az.y, bz.y));
-					hl = (vmax(dl, t_min) <= fl) && (dl < lim);
-					hr = (vmax(dr, t_min) <= fr) && (dr < lim);
-				} else {
-					auto slab = [&](float a_x, float b_x, float a_y, float b_y, float a_z, float b_z, float &entry) {
-						float nx = (a_x < b_x) ? a_x : b_x, fx = (b_x < a_x) ? a_x : b_x;
-						float ny = (a_y < b_y) ? a_y : b_y, fy = (b_y < a_y) ? a_y : b_y;
-						float nz = (a_z < b_z) ? a_z : b_z, fz = (b_z < a_z) ? a_z : b_z;
-						float t1 = (nx < ny) ? ny : nx;
-						t1 = (nz < t1) ? t1 : nz;
-						float t2 = (fx < fy) ? fx : fy;
-						t2 = (fz < t2) ? fz : t2;
-						entry = t1;
-						bool hit = !(t1 > t2) && !(t2 < t_min) && !(t1 > t_max);
-						if (!any_lane) hit = hit && t1 < best_t;  // bvh2.cpp:432-433; not in any_hit (:476-477)
-						return hit;
-					};
-					hl = slab(ax.x, bx.x, ay.x, by.x, az.x, bz.x, dl);
-					hr = slab(ax.y, bx.y, ay.y, by.y, az.y, bz.y, dr);
-				}
-				// bvh2.cpp:434-446: both hit -> nearer first, the right child on a tie, the other one pending
-				const bool left_first = hl && ((dl < dr) || !hr);
-				const int32_t first = left_first ? link_l : link_r;
-				const int32_t second = left_first ? link_r : link_l;
-				if (hl && hr) push(second);
-				if (hl || hr)
-					cur = first;
-				else
-					advance();
-			};
+			if (COUNT) ++n_inner;
+			auto pair = [](uint32_t u, uint32_t v) { return f32x2{__uint_as_float(u), __uint_as_float(v)}; };
+			// .x = left child, .y = right child; (box - o) * id as in libgi/intersect.h:210-221
+			const f32x2 ax = (pair(q0.x, q0.y) - f32x2{ox, ox}) * f32x2{ix, ix};
+			const f32x2 ay = (pair(q0.z, q0.w) - f32x2{oy, oy}) * f32x2{iy, iy};
+			const f32x2 az = (pair(q1.x, q1.y) - f32x2{oz, oz}) * f32x2{iz, iz};
+			const f32x2 bx = (pair(q1.z, q1.w) - f32x2{ox, ox}) * f32x2{ix, ix};
+			const f32x2 by = (pair(q2.x, q2.y) - f32x2{oy, oy}) * f32x2{iy, iy};
+			const f32x2 bz = (pair(q2.z, q2.w) - f32x2{oz, oz}) * f32x2{iz, iz};
+			float dl, dr;
+			if (PLAIN) {
+				// no NaN possible: the selects of intersect.h:212-228 are exact min / max, and
+				// !(t1 > t2) && !(t2 < t_min) && !(t1 > t_max) [&& t1 < closest t] folds into two compares
+				dl = vmax3(vmin(ax.x, bx.x), vmin(ay.x, by.x), vmin(az.x, bz.x));
+				dr = vmax3(vmin(ax.y, bx.y), vmin(ay.y, by.y), vmin(az.y, bz.y));
+				const float fl = vmin3(vmax(ax.x, bx.x), vmax(ay.x, by.x), vmax(az.x, bz.x));
+				const float fr = vmin3(vmax(ax.y, bx.y), vmax(ay.y, by.y), vmax(az.y, bz.y));
+				hl = (vmax(dl, t_min) <= fl) && (dl < lim);
+				hr = (vmax(dr, t_min) <= fr) && (dr < lim);
+			} else {
+				auto slab = [&](float a_x, float b_x, float a_y, float b_y, float a_z, float b_z, float &entry) {
+					float nx = (a_x < b_x) ? a_x : b_x, fx = (b_x < a_x) ? a_x : b_x;
+					float ny = (a_y < b_y) ? a_y : b_y, fy = (b_y < a_y) ? a_y : b_y;
+					float nz = (a_z < b_z) ? a_z : b_z, fz = (b_z < a_z) ? a_z : b_z;
+					float t1 = (nx < ny) ? ny : nx;
+					t1 = (nz < t1) ? t1 : nz;
+					float t2 = (fx < fy) ? fx : fy;
+					t2 = (fz < t2) ? fz : t2;
+					entry = t1;
+					bool hit = !(t1 > t2) && !(t2 < t_min) && !(t1 > t_max);
+					if (!any_lane) hit = hit && t1 < best_t;  // bvh2.cpp:432-433; not in any_hit (:476-477)
+					return hit;
+				};
+				hl = slab(ax.x, bx.x, ay.x, by.x, az.x, bz.x, dl);
+				hr = slab(ax.y, bx.y, ay.y, by.y, az.y, bz.y, dr);
+			}
+			// bvh2.cpp:434-446: both hit -> nearer first, the right child on a tie, the other one pending
+			left_first = hl && ((dl < dr) || !hr);
+		};
+		// the twelve box planes of inner node `cur` (and its links, where they are not implied), from the copy in LDS or
+		// from memory. (All loads from memory go out before the first LDS read, which has to wait for them: the compiler
+		// cannot know that the two write different lanes of the same registers.)
+		auto fetch = [&](bool with_links, u32x4 &q0, u32x4 &q1, u32x4 &q2, u32x2 &links) {
+			if (cur >= top_nodes) {
+				const int voff = cur << 6;
+				q0 = __builtin_amdgcn_raw_buffer_load_b128(node_rsrc, voff, 0, 0);
+				q1 = __builtin_amdgcn_raw_buffer_load_b128(node_rsrc, voff + 16, 0, 0);
+				q2 = __builtin_amdgcn_raw_buffer_load_b128(node_rsrc, voff + 32, 0, 0);
+				if (with_links) links = __builtin_amdgcn_raw_buffer_load_b64(node_rsrc, voff + 48, 0, 0);
+			} else {
+				const u32x4 *rec = reinterpret_cast<const u32x4 *>(s_mem + top_offset + __umul24((uint32_t)cur, 48u));
+				q0 = rec[0], q1 = rec[1], q2 = rec[2];
+				if (with_links) links = s_links[cur - implicit_limit];
+				if (COUNT) ++n_top;
+			}
+		};
+
+		// ---- inner nodes: every lane standing on an inner node takes one step per iteration; the loop ends once `leave`
+		// lanes have left it (reached a leaf or finished their ray), or nobody is left. Lanes on nodes whose links must
+		// be fetched (the few levels below the heap-numbered ones) sit out until link_min of them have gathered or the
+		// loop would end without them: the link fetch is one more vector memory instruction for the whole wave, which
+		// most iterations then do not pay. ----------------------------------------------------------------------------
+		auto inner_phase = [&](auto plain_tag) {
+			const int keep_going = max(0, n_busy - leave);
 			for (;;) {
 				const bool at_inner = cur >= 0;
-				if ((int)__popcll(__ballot(at_inner)) <= keep_going) break;
+				const bool needs_links = cur >= implicit_limit;
+				const int n_in = (int)__popcll(__ballot(at_inner));
+				if (n_in <= keep_going) break;
+				const int n_links = (int)__popcll(__ballot(needs_links));
+				const bool serve_links = n_links >= link_min || n_in - n_links <= keep_going;
 #ifdef RTGI_DIAG
 				if (more) ++dg_it_more, dg_ln_more += __popcll(__ballot(at_inner));
 				else ++dg_it_drain, dg_ln_drain += __popcll(__ballot(at_inner));
 #endif
-				if (at_inner) {
-					// (One pass over the step code for all lanes, whether their node comes from LDS or from memory: letting
-					// the lanes inside the LDS part take extra steps while the others' loads are under way was measured and
-					// costs 3 % at one extra pass and 20 % at three -- the passes with few active lanes take vector issue
-					// slots from the other three waves of the SIMD.)
+				if (at_inner && (!needs_links || serve_links)) {
 					u32x4 q0, q1, q2;
-					u32x2 q3;
-					if (cur < top_nodes) {
-						const u32x4 l3 = s_top[3 * top_nodes + cur];
-						q0 = s_top[cur], q1 = s_top[top_nodes + cur], q2 = s_top[2 * top_nodes + cur], q3 = u32x2{l3.x, l3.y};
-						if (COUNT) ++n_top;
-					} else {
-						const int voff = cur << 6;
-						q0 = __builtin_amdgcn_raw_buffer_load_b128(node_rsrc, voff, 0, 0);
-						q1 = __builtin_amdgcn_raw_buffer_load_b128(node_rsrc, voff + 16, 0, 0);
-						q2 = __builtin_amdgcn_raw_buffer_load_b128(node_rsrc, voff + 32, 0, 0);
-						q3 = __builtin_amdgcn_raw_buffer_load_b64(node_rsrc, voff + 48, 0, 0);
-					}
-					step(q0, q1, q2, (int32_t)q3.x, (int32_t)q3.y);
+					u32x2 links = u32x2{(uint32_t)cur << 1, ((uint32_t)cur << 1) | 1u};  // heap-numbered nodes: no link fetch
+					fetch(needs_links, q0, q1, q2, links);
+					bool hl, hr, left_first;
+					boxes(plain_tag, q0, q1, q2, hl, hr, left_first);
+					const int32_t first = (int32_t)(left_first ? links.x : links.y);
+					const int32_t second = (int32_t)(left_first ? links.y : links.x);
+#if RTGI_TRAIL
+					if (hl || hr) {
+						if (!needs_links) {  // children on the heap: the pending one is a bit
+							trail = (trail << 1) | (uint32_t)(hl && hr);
+							anchor = (uint32_t)first;
+						} else if (hl && hr)
+							push(second);
+						cur = first;
+					} else
+						advance();
+#else
+					if (hl && hr) push(second);
+					if (hl || hr)
+						cur = first;
+					else
+						advance();
+#endif
 				}
 			}
 		};
