@@ -343,6 +343,12 @@ int rtgi_hip_profile_end(rtgi_hip_tracer *h, double *kernel_ms_total, uint32_t *
  * from the kernel's copy of the top of the tree in LDS instead of the vector cache. Waits for the GPU. */
 int rtgi_hip_profile_work(rtgi_hip_tracer *h, uint64_t out[4]);
 
+/* The stack of the traversal (the reference keeps 25 slots per ray and does not check them, bvh2.cpp:419,469): here as
+ * many pending nodes per ray as the tree is deep, the first *lds_levels of them in LDS and, for deeper trees,
+ * *spill_levels more in a global area. *pushes = the pushes of the counting launches since the last profile_begin
+ * that went to the global area (0 for a tree that fits in LDS); waits for the GPU. Any pointer may be NULL. */
+int rtgi_hip_profile_spills(rtgi_hip_tracer *h, uint64_t *pushes, uint32_t *lds_levels, uint32_t *spill_levels);
+
 /* Text of the last error on this handle (h may be NULL: last error of a failed create). */
 const char *rtgi_hip_last_error(const rtgi_hip_tracer *h);
 

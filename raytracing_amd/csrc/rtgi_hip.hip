@@ -194,7 +194,7 @@ struct rtgi_hip_tracer {
 	float reorder_min_pops = 120.0f;
 	std::vector<rtgi_ray> probe_rays;
 	uint32_t node_bytes = 0, tri_bytes = 0;
-	int refill_min = 24, leaf_min = 12, drain_leaf_min = 4, link_min = 4;
+	int refill_min = 24, leaf_min = 12, drain_leaf_min = 4;
 	bool top_in_lds = true;
 	uint32_t blocks_per_cu = 1;
 	// division of a workgroup's LDS (set at upload from the tree's depth and size, see trace_kernel.h)
@@ -241,6 +241,9 @@ struct DeviceScope {
 			status = hipSuccess;
 			return;
 		}
+		// (an error some earlier call on this thread chose to ignore is not this call's: launches below are checked with
+		// hipGetLastError, which would hand it to them)
+		(void)hipGetLastError();
 		status = hipGetDevice(&previous);
 		if (status != hipSuccess) previous = -1;
 		status = previous == device ? hipSuccess : hipSetDevice(device);
@@ -287,7 +290,6 @@ void read_tunables(rtgi_hip_tracer *h) {
 	h->refill_min = number("RTGI_HIP_REFILL_MIN", 1, 64, h->refill_min);
 	h->leaf_min = number("RTGI_HIP_LEAF_MIN", 1, 64, h->leaf_min);
 	h->drain_leaf_min = number("RTGI_HIP_DRAIN_LEAF_MIN", 1, 64, h->drain_leaf_min);
-	h->link_min = number("RTGI_HIP_LINK_MIN", 1, 64, h->link_min);
 	h->n_segments = number("RTGI_HIP_SEGMENTS", 1, 8, 8) == 1 ? 1u : 8u;
 	h->top_in_lds = number("RTGI_HIP_TOP_IN_LDS", 0, 1, 1) != 0;
 	h->force_stack_levels = number("RTGI_HIP_STACK_LEVELS", 0, 64, 0);
@@ -317,10 +319,8 @@ int upload_flat(rtgi_hip_tracer *h, const rtgi::FlatTree &flat, const rtgi::Scen
 	// (what one workgroup may ask for: the opt-in limit where the runtime reports one, else the 64 KiB every GPU grants)
 	const uint32_t lds_block = prop.sharedMemPerBlockOptin >= 65536 ? (uint32_t)prop.sharedMemPerBlockOptin : 65536u;
 	const uint32_t lds_budget = std::min<uint32_t>({lds_cu / h->blocks_per_cu, lds_block, 160u << 10});
-	// (Nodes of the heap-numbered levels at the top of the tree wait as bits in a register: only the inner levels from
-	// the last heap-numbered one down push into memory, one entry each at most.)
 	const bool implicit_links = !getenv("RTGI_HIP_NO_IMPLICIT_LINKS") && flat.heap_levels >= 2;
-	const uint32_t stack_need = std::max<uint32_t>(implicit_links && rtgi_dev::TRAIL ? flat.depth - (flat.heap_levels - 1) : flat.depth, 1);
+	const uint32_t stack_need = std::max<uint32_t>(flat.depth, 1);
 	h->stack_levels = stack_need <= (uint32_t)rtgi_dev::MAX_STACK_LDS ? stack_need : (uint32_t)rtgi_dev::DEEP_STACK_LDS;
 	if (h->force_stack_levels) h->stack_levels = (uint32_t)h->force_stack_levels;
 	while (h->stack_levels > 1 && (size_t)h->stack_levels * BLOCK * sizeof(int32_t) > lds_budget) --h->stack_levels;
@@ -660,7 +660,6 @@ int launch_batches(rtgi_hip_tracer *h, const BatchView *given, uint32_t n_given,
 	a.refill_min = h->refill_min;
 	a.leaf_min = h->leaf_min;
 	a.drain_leaf_min = h->drain_leaf_min;
-	a.link_min = h->implicit_limit ? h->link_min : 1;  // (a tree without heap-numbered levels: every inner node has links)
 	a.top_nodes = (int32_t)h->top_nodes;
 	a.implicit_limit = (int32_t)h->implicit_limit;
 	a.stack_levels = (int32_t)h->stack_levels;
@@ -968,6 +967,27 @@ rtgi_hip_tracer *rtgi_hip_create(int device, int layout, int esc) {
 		std::lock_guard<std::mutex> lock(g_scratch_guard);
 		if (!g_scratch_ptr[device]) {
 			DeviceScope device_scope(device);
+			// Every kernel of the library is looked up once here, by one thread: the runtime loads a kernel when it is
+			// first used, and first launches of one kernel from several host threads at the same moment (the frame
+			// level drives each GPU from a thread of its own) have been seen to fail with "invalid argument".
+			if (device_scope.status == hipSuccess) {
+				using namespace rtgi_dev;
+				const void *kernels[] = {
+				    (const void *)&trace_kernel<0, false, false>, (const void *)&trace_kernel<0, false, true>, (const void *)&trace_kernel<0, true, false>,
+				    (const void *)&trace_kernel<0, true, true>, (const void *)&trace_kernel<1, false, false>, (const void *)&trace_kernel<1, false, true>,
+				    (const void *)&trace_kernel<1, true, false>, (const void *)&trace_kernel<1, true, true>, (const void *)&trace_kernel<2, false, false>,
+				    (const void *)&trace_kernel<2, false, true>, (const void *)&ray_keys_kernel, (const void *)&segment_bounds_kernel,
+				    (const void *)&camera_rays_kernel, (const void *)&shadow_rays_kernel, (const void *)&pixel_offsets_kernel,
+				    (const void *)&bounce_count_kernel, (const void *)&scan_kernel, (const void *)&bounce_write_kernel,
+				    (const void *)&shade_primary_kernel, (const void *)&shade_local_kernel, (const void *)&shade_local_brdf_kernel,
+				    (const void *)&framebuffer_add_kernel, (const void *)&path_begin_kernel, (const void *)&path_add_kernel,
+				    (const void *)&path_extend_kernel, (const void *)&framebuffer_scatter_kernel, (const void *)&framebuffer_sums_kernel,
+				    (const void *)&framebuffer_accumulate_kernel, (const void *)&framebuffer_rgb8_kernel};
+				for (const void *k : kernels) {
+					hipFuncAttributes attr;
+					if (hipFuncGetAttributes(&attr, k) != hipSuccess) (void)hipGetLastError();  // (a launch will report it)
+				}
+			}
 			void *ptr = nullptr;
 			hipError_t e = device_scope.status;
 			if (e == hipSuccess) e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
@@ -1785,8 +1805,8 @@ int rtgi_hip_profile_begin(rtgi_hip_tracer *h) {
 	if (h->device < 0) return fail(h, RTGI_ERR_DEVICE, "host-only handle: needs a GPU");
 	DeviceScope device_scope(h->device);
 	HIP_TRY(h, device_scope.status);
-	if (!h->d_totals) HIP_TRY(h, hipMalloc((void **)&h->d_totals, 4 * sizeof(unsigned long long)));
-	HIP_TRY(h, hipMemset(h->d_totals, 0, 4 * sizeof(unsigned long long)));
+	if (!h->d_totals) HIP_TRY(h, hipMalloc((void **)&h->d_totals, 8 * sizeof(unsigned long long)));
+	HIP_TRY(h, hipMemset(h->d_totals, 0, 8 * sizeof(unsigned long long)));
 	h->profiling = true;
 	h->events_used = 0;
 	return RTGI_OK;
@@ -1802,6 +1822,23 @@ int rtgi_hip_profile_work(rtgi_hip_tracer *h, uint64_t out[4]) {
 	unsigned long long v[4];
 	HIP_TRY(h, hipMemcpy(v, h->d_totals, sizeof(v), hipMemcpyDeviceToHost));
 	for (int k = 0; k < 4; ++k) out[k] = v[k];
+	return RTGI_OK;
+}
+
+int rtgi_hip_profile_spills(rtgi_hip_tracer *h, uint64_t *pushes, uint32_t *lds_levels, uint32_t *spill_levels) {
+	if (!h) return RTGI_ERR_INVALID;
+	if (h->device < 0) return fail(h, RTGI_ERR_DEVICE, "host-only handle: needs a GPU");
+	if (lds_levels) *lds_levels = h->stack_levels;
+	if (spill_levels) *spill_levels = h->spill_levels;
+	if (!pushes) return RTGI_OK;
+	*pushes = 0;
+	if (!h->d_totals) return RTGI_OK;  // (no profile_begin yet: nothing has been counted)
+	DeviceScope device_scope(h->device);
+	HIP_TRY(h, device_scope.status);
+	HIP_TRY(h, hipDeviceSynchronize());
+	unsigned long long v = 0;
+	HIP_TRY(h, hipMemcpy(&v, h->d_totals + 4, sizeof(v), hipMemcpyDeviceToHost));
+	*pushes = v;
 	return RTGI_OK;
 }
 

@@ -15,10 +15,9 @@
 //    subtracts / multiplies for both children;
 //  * loads go through buffer descriptors: a 32-bit per-lane offset instead of 64-bit address arithmetic,
 //    and an out-of-range index reads zeros instead of faulting;
-//  * the pending-node stack keeps its top in a register; pending nodes of the heap-numbered levels are one bit
-//    each in a register (see below), the rest lives in LDS as [level][lane] (any mix of depths is conflict-free);
-//    trees with more than MAX_STACK_LDS levels below the heap-numbered ones use the DEEP variant, which continues
-//    the stack in a global area sized from the tree depth, so the stack cannot overflow;
+//  * the pending-node stack keeps its top in a register and the rest in LDS as [level][lane] (any mix of
+//    depths is conflict-free); trees deeper than MAX_STACK_LDS use the DEEP variant, which continues the stack
+//    in a global area sized from the tree depth, so the stack cannot overflow;
 //  * the first nodes of the breadth-first numbering, which every ray visits, are read from a copy in LDS (as
 //    many as fit beside the stacks);
 //  * the levels at the top of the tree that consist of inner nodes only are numbered like a heap, so the children of
@@ -48,10 +47,6 @@ constexpr int BLOCK = RTGI_BLOCK;  // threads per workgroup
 #define RTGI_WAVES_PER_SIMD (RTGI_BLOCK / 256)
 #endif
 constexpr int WAVES_PER_SIMD = RTGI_WAVES_PER_SIMD;  // resident waves per SIMD the register budget is kept within (all workgroups of a CU together)
-#ifndef RTGI_TRAIL
-#define RTGI_TRAIL 0  // 1: pending nodes of the heap-numbered levels are bits in a register instead of stack entries
-#endif
-constexpr bool TRAIL = RTGI_TRAIL;
 constexpr int MAX_STACK_LDS = 24;  // at most this many pending nodes per lane in LDS (beyond the one in a register)
 constexpr int DEEP_STACK_LDS = 20; // trees deeper than MAX_STACK_LDS: this many in LDS, the rest in the global spill area
 constexpr int COUNTER_STRIDE = 32;
@@ -71,7 +66,7 @@ struct TraceArgs {
 	float4 *hits;           // closest_hit output
 	uint8_t *occluded;      // any_hit output
 	uint32_t *counts;       // optional: 2 per ray
-	unsigned long long *totals;  // optional, counting kernels only: sums over the launch, see finish()
+	unsigned long long *totals;  // optional, counting kernels only: five sums over the launch, see the end of the kernel
 	int32_t *spill;         // DEEP only: [level - stack_levels][global lane]
 	uint32_t *ray_counter;  // n_segments counters, COUNTER_STRIDE words apart (one cache line each)
 	uint32_t n_rays;
@@ -92,7 +87,6 @@ struct TraceArgs {
 	int32_t top_nodes;      // visits to inner nodes 0 .. top_nodes-1 are served from a copy in LDS
 	int32_t stack_levels;   // pending-node slots per lane in LDS; dynamic LDS: see lds_bytes_for()
 	int32_t implicit_limit; // inner nodes below this index are numbered like a heap: children 2i and 2i + 1, no link fetch
-	int32_t link_min;       // lanes on other inner nodes take their step once this many have gathered
 #ifdef RTGI_DIAG
 	unsigned long long *diag;  // diagnostic build only: 8 counters summed over all waves
 #endif
@@ -139,11 +133,7 @@ __host__ __device__ inline size_t lds_bytes_for(uint32_t stack_levels, uint32_t 
 
 // MODE 0: closest_hit, 1: any_hit, 2: a launch over several batches, each of one kind or the other.
 template <int MODE, bool COUNT, bool DEEP>
-#ifdef RTGI_PLAIN_BOUNDS
-__global__ __launch_bounds__(BLOCK) void trace_kernel(TraceArgs a) {
-#else
 __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void trace_kernel(TraceArgs a) {
-#endif
 	constexpr bool MIXED = MODE == 2;
 	extern __shared__ __align__(16) unsigned char s_mem[];
 	const int32_t stack_levels = a.stack_levels;
@@ -163,7 +153,6 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void trace_kernel(TraceArgs 
 	const int32_t implicit_limit = a.implicit_limit;
 	u32x2 *const s_links = reinterpret_cast<u32x2 *>(s_top + 3 * top_nodes);  // [node - implicit_limit], nodes of the copy only
 	const uint32_t top_offset = (uint32_t)stack_levels * BLOCK * sizeof(int32_t);
-	const uint32_t heap_end = 2u * (uint32_t)implicit_limit;  // heap-numbered nodes have indices below this
 	if (top_nodes) {
 		for (int i = tid; i < 3 * top_nodes; i += BLOCK) {
 			const int node = i / 3, quad = i - 3 * node;
@@ -184,14 +173,9 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void trace_kernel(TraceArgs 
 	const float4 *my_rays = a.rays;
 	void *my_out = nullptr;     // MIXED: where this lane's result goes
 	uint32_t n_inner = 0, n_tri = 0, n_top = 0;
-	unsigned long long sum_rays = 0, sum_inner = 0, sum_tri = 0, sum_top = 0;  // COUNT: over all rays of this lane
+	unsigned long long sum_rays = 0, sum_inner = 0, sum_tri = 0, sum_top = 0, sum_spill = 0;  // COUNT: over all rays of this lane
 	int32_t cur = IDLE;
 	int sp = 0;          // pending entries in memory (the next node to visit is `cur`, in a register)
-	// Pending nodes inside the heap-numbered levels need no memory: the sibling of heap node i is i ^ 1 and its
-	// parent i >> 1, so one bit per level says whether the sibling of the path's node on that level still waits.
-	// anchor = the deepest heap-numbered node on the current path; bit j of trail belongs to anchor >> j. Everything
-	// pushed below the heap levels lies deeper than any of these, so the stack in memory is emptied first.
-	uint32_t anchor = 0, trail = 0;
 	bool plain = true;   // no NaN can arise in this ray's slab tests
 	bool more = true;    // wave-uniform: some segment may still have rays
 	// Each XCD has its own L2. Waves of one XCD draw rays from the same contiguous part of the batch, so that
@@ -203,8 +187,10 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void trace_kernel(TraceArgs 
 	auto push = [&](int32_t v) {
 		if (!DEEP || sp < stack_levels)
 			s_stack[sp * BLOCK + tid] = v;
-		else
+		else {
 			a.spill[(size_t)(sp - stack_levels) * a.spill_stride + gl] = v;
+			if (COUNT) ++sum_spill;
+		}
 		++sp;
 	};
 	auto pop = [&]() -> int32_t {
@@ -229,16 +215,11 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void trace_kernel(TraceArgs 
 		}
 		cur = IDLE;
 	};
-	auto advance = [&]() {  // next pending node (the deepest one), or the ray is done
-		if (sp != 0)
-			cur = pop();
-		else if (TRAIL && trail != 0) {
-			const int up = __builtin_ctz(trail);
-			anchor = (anchor >> up) ^ 1u;
-			trail = (trail >> up) ^ 1u;
-			cur = (int32_t)anchor;
-		} else
+	auto advance = [&]() {  // next pending node, or the ray is done
+		if (sp == 0)
 			finish();
+		else
+			cur = pop();
 	};
 
 #ifdef RTGI_DIAG
@@ -308,7 +289,6 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void trace_kernel(TraceArgs 
 				n_inner = n_tri = n_top = 0;
 				cur = a.root_ref;
 				sp = 0;
-				anchor = (uint32_t)a.root_ref, trail = 0;
 				lim = any_lane ? lim0 : __builtin_fminf(best_t, lim0);
 			}
 		}
@@ -324,7 +304,6 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void trace_kernel(TraceArgs 
 		// were busy when it began stand outside it.
 		const int n_busy = (int)__popcll(busy);
 		const int leave = __builtin_amdgcn_readfirstlane(more ? a.leaf_min : a.drain_leaf_min);
-		const int link_min = __builtin_amdgcn_readfirstlane(more ? a.link_min : 1);
 
 		// one step of one lane: the two child boxes of its node against its ray; which ones to enter, and which one first
 		auto boxes = [&](auto plain_tag, const u32x4 q0, const u32x4 q1, const u32x4 q2, bool &hl, bool &hr, bool &left_first) {
@@ -387,48 +366,29 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void trace_kernel(TraceArgs 
 		};
 
 		// ---- inner nodes: every lane standing on an inner node takes one step per iteration; the loop ends once `leave`
-		// lanes have left it (reached a leaf or finished their ray), or nobody is left. Lanes on nodes whose links must
-		// be fetched (the few levels below the heap-numbered ones) sit out until link_min of them have gathered or the
-		// loop would end without them: the link fetch is one more vector memory instruction for the whole wave, which
-		// most iterations then do not pay. ----------------------------------------------------------------------------
+		// lanes have left it (reached a leaf or finished their ray), or nobody is left -----------------------------------
 		auto inner_phase = [&](auto plain_tag) {
 			const int keep_going = max(0, n_busy - leave);
 			for (;;) {
 				const bool at_inner = cur >= 0;
-				const bool needs_links = cur >= implicit_limit;
-				const int n_in = (int)__popcll(__ballot(at_inner));
-				if (n_in <= keep_going) break;
-				const int n_links = (int)__popcll(__ballot(needs_links));
-				const bool serve_links = n_links >= link_min || n_in - n_links <= keep_going;
+				if ((int)__popcll(__ballot(at_inner)) <= keep_going) break;
 #ifdef RTGI_DIAG
 				if (more) ++dg_it_more, dg_ln_more += __popcll(__ballot(at_inner));
 				else ++dg_it_drain, dg_ln_drain += __popcll(__ballot(at_inner));
 #endif
-				if (at_inner && (!needs_links || serve_links)) {
+				if (at_inner) {
 					u32x4 q0, q1, q2;
 					u32x2 links = u32x2{(uint32_t)cur << 1, ((uint32_t)cur << 1) | 1u};  // heap-numbered nodes: no link fetch
-					fetch(needs_links, q0, q1, q2, links);
+					fetch(cur >= implicit_limit, q0, q1, q2, links);
 					bool hl, hr, left_first;
 					boxes(plain_tag, q0, q1, q2, hl, hr, left_first);
 					const int32_t first = (int32_t)(left_first ? links.x : links.y);
 					const int32_t second = (int32_t)(left_first ? links.y : links.x);
-#if RTGI_TRAIL
-					if (hl || hr) {
-						if (!needs_links) {  // children on the heap: the pending one is a bit
-							trail = (trail << 1) | (uint32_t)(hl && hr);
-							anchor = (uint32_t)first;
-						} else if (hl && hr)
-							push(second);
-						cur = first;
-					} else
-						advance();
-#else
 					if (hl && hr) push(second);
 					if (hl || hr)
 						cur = first;
 					else
 						advance();
-#endif
 				}
 			}
 		};
@@ -486,9 +446,9 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void trace_kernel(TraceArgs 
 				advance();
 		}
 	}
-	if (COUNT && a.totals) {  // rays, inner nodes popped, triangles tested, inner nodes read from the copy in LDS
-		unsigned long long v[4] = {sum_rays, sum_inner, sum_tri, sum_top};
-		for (int k = 0; k < 4; ++k) {
+	if (COUNT && a.totals) {  // rays, inner nodes popped, triangles tested, inner nodes read from the copy in LDS, pushes beyond the LDS stack
+		unsigned long long v[5] = {sum_rays, sum_inner, sum_tri, sum_top, sum_spill};
+		for (int k = 0; k < 5; ++k) {
 			for (int step = 32; step > 0; step >>= 1) v[k] += __shfl_xor(v[k], step);
 			if (lane == 0) atomicAdd(a.totals + k, v[k]);
 		}

@@ -269,3 +269,47 @@ def random_rays(n, seed=7, extent=10.0):
     rays[:, 6] = 1e-4
     rays[:, 7] = np.finfo(np.float32).max
     return rays
+
+
+def stadium_sheets(n_tris=1 << 22, sheets=40, seed=11):
+    """Deep-stack scene for spatial-median trees: `sheets` parallel sheets facing +x at x = -2^i, each twice as large
+    as the one before and tessellated into n_tris / sheets jittered triangles. A spatial-median split along x peels the
+    farthest sheet off at every level, so the tree is a chain of `sheets` levels with a full subtree hanging off each;
+    a ray travelling along -x enters both children at every level of the chain and leaves the farther one pending:
+    the traversal stack holds one entry per sheet still ahead, far more than fit in the LDS part of the stack (and than
+    the 25 slots of the reference's own fixed stack, rt/bbvh-base/bvh2.cpp:419)."""
+    rs = np.random.RandomState(seed)
+    k = max(2, int(np.sqrt(n_tris / sheets / 2)))
+    parts = []
+    for i in range(sheets):
+        x, s = -(2.0 ** i), 0.25 * 2.0 ** i
+        jitter = rs.uniform(-0.2, 0.2, size=(k + 1, k + 1, 1)) * (2.0 * s / k)
+
+        def wobble(S, T, jitter=jitter, s=s):
+            # (in-plane jitter of the grid points: unequal centres, no exact ties for the builder's partition)
+            return np.concatenate([0 * jitter, jitter, np.roll(jitter, 1, axis=0)], axis=-1)
+        parts.append(_quad_grid([x, -s, -s], [0, 2 * s, 0], [0, 0, 2 * s], k, k, displace=wobble))
+    return _finish(np.concatenate(parts, axis=0))
+
+
+def stadium_rays(n, seed=3, sheets=40, along=0.6):
+    """Rays for stadium_sheets: a share `along` of them starts in front of the first sheet and runs along -x through
+    all sheets (slightly spread, so that they cross each sheet inside its extent), the rest starts between the sheets
+    in random directions."""
+    rs = np.random.RandomState(seed)
+    rays = np.empty((n, 8), np.float32)
+    n_along = int(n * along)
+    o = np.zeros((n, 3))
+    d = np.zeros((n, 3))
+    o[:n_along, 0] = 2.0
+    o[:n_along, 1:3] = rs.uniform(-0.2, 0.2, size=(n_along, 2))
+    d[:n_along] = np.concatenate([-np.ones((n_along, 1)), rs.uniform(-0.2, 0.2, size=(n_along, 2))], axis=1)
+    m = n - n_along
+    level = rs.uniform(0, sheets - 1, size=m)
+    o[n_along:, 0] = -(2.0 ** level)
+    o[n_along:, 1:3] = rs.uniform(-0.2, 0.2, size=(m, 2)) * (2.0 ** level)[:, None]
+    d[n_along:] = rs.normal(size=(m, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays[:, 0:3], rays[:, 3:6] = o, d
+    rays[:, 6], rays[:, 7] = 1e-4, np.finfo(np.float32).max
+    return rays

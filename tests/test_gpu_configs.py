@@ -7,7 +7,9 @@
 3. Sponza-class scene of ~262 k triangles, 1280x720, one diffuse bounce per primary hit: closest_hit on the
    incoherent bounce batch;
 4. the 2^20-triangle soup at 1920x1080 with its bounce batch (the workload bench.py times);
-5. multi-million-triangle deep tree with mixed batches (test_gpu_parity.py).
+5. multi-million-triangle deep trees with mixed closest_hit / any_hit batches: a skewed scene whose tree is deep but
+   whose rays keep few nodes pending (test_gpu_parity.py), and below a scene built so that most rays hold more
+   pending nodes than the LDS part of the stack has levels (and than the reference's fixed 25 slots).
 
 Bar: hit records bit-identical to the oracle's on a sample of at least 1/16 of the batch (all of it where the
 oracle finishes in seconds), plus properties that hold for every ray."""
@@ -141,7 +143,8 @@ def test_config4_soup_1m_bounce_batch_1080p():
     cam = (np.array([0, 0, -1], np.float32), [0, 0, 0], [0, 1, 0], 65.0, 1920, 1080)
     _, _, d_bounce = _bounce_batch(t, cam, sample=0)
     assert d_bounce.shape[0] > 1300000
-    hits, cnt = _check_bounce_batch(t, o, pos, tri_reported, d_bounce, 16, "soup 1M bounce")
+    # (every ray against the CPU tracer: hit records, any-hit bytes and per-ray pop / test counts, 1.45 M of each)
+    hits, cnt = _check_bounce_batch(t, o, pos, tri_reported, d_bounce, 1, "soup 1M bounce")
     assert 150 < cnt[:, 0].mean() < 250                            # incoherent rays: ~200 inner nodes each
     # the entry point that allocates nothing gives the same records
     import torch
@@ -149,4 +152,58 @@ def test_config4_soup_1m_bounce_batch_1080p():
     t.closest_hit_device_noalloc(d_bounce, d_hits)
     torch.cuda.synchronize()
     assert_hits_equal(_hits_of(d_hits), hits, "noalloc, soup 1M bounce")
+    t.close()
+
+
+def test_config5_deep_stack_scene_spills_at_4m_triangles():
+    """2^22 triangles in 40 sheets of doubling size under spatial-median splits: a chain of 40 levels with a full
+    subtree at each. Rays along the chain keep one node pending per sheet ahead, so most of them push beyond the
+    levels of the stack that live in LDS. closest_hit and any_hit batches share launches; the oracle (growable stack)
+    checks a sixteenth of the rays including per-ray counts, properties cover all of them."""
+    import torch
+    pos, tri, _ = scenes.stadium_sheets(1 << 22, sheets=40)
+    assert len(tri) > 4000000
+    t = tracer.HipBvhTracer(layout="indexed")
+    assert t.interprete("bvh", "sm")
+    t.build(pos, tri)
+    _, lds_levels, spill_levels = t.profile_spills()
+    assert t.depth > 40 and spill_levels > 0 and lds_levels + spill_levels == t.depth
+    n = 1 << 20
+    rays = scenes.stadium_rays(n, seed=3, sheets=40)
+    d_rays = torch.from_numpy(rays).cuda()
+    d_hits = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+    d_occ = torch.empty(n, dtype=torch.uint8, device="cuda")
+    d_cnt = torch.zeros((n, 2), dtype=torch.int32, device="cuda")
+    # one launch over four batches, closest_hit and any_hit interleaved (each on the whole ray set, in halves)
+    half = n // 2
+    t.trace_batches_device([(d_rays[:half], d_hits[:half], "closest"), (d_rays[:half], d_occ[:half], "any"),
+                            (d_rays[half:], d_occ[half:], "any"), (d_rays[half:], d_hits[half:], "closest")])
+    torch.cuda.synchronize()
+    hits, occ = _hits_of(d_hits), d_occ.cpu().numpy()
+    t.profile_begin()
+    d_hits2 = torch.empty_like(d_hits)
+    t.closest_hit_device(d_rays, d_hits2, d_cnt)
+    torch.cuda.synchronize()
+    work = t.profile_work()
+    pushes, _, _ = t.profile_spills()
+    t.profile_end()
+    assert torch.equal(d_hits2, d_hits)
+    o = orc.Bbvh(pos, tri, layout="indexed", split="sm")
+    sample = np.arange(0, n, 16)
+    want, want_counts, max_stack = o.closest_hit(rays[sample], counts=True, max_stack=True)
+    assert_hits_equal(hits[sample], want, "deep-stack scene sample")
+    assert (d_cnt.cpu().numpy().astype(np.uint32)[sample] == want_counts[:, 0:2]).all()
+    assert (occ[sample] == o.any_hit(rays[sample])).all()
+    beyond_lds = max_stack > lds_levels
+    assert beyond_lds.mean() > 0.4 and max_stack.max() > 25     # most rays need the spill area, and more than 25 slots
+    assert pushes >= 16 * int(beyond_lds.sum()) * 0.9            # every such ray pushed there at least once
+    assert pushes < work[1]                                      # (a push follows an inner-node visit)
+    valid = hits["t"] != FLT_MAX
+    assert (occ == valid).all() and 0.3 < valid.mean() < 0.95
+    # nothing lies in front of a closest hit -- up to the few ulp by which the reference's traversal itself may keep the
+    # farther of two hits on coplanar neighbours (it enters a box only if its entry distance is BELOW the closest t so
+    # far, bvh2.cpp:432-433), which a tessellated sheet is full of
+    short = rays[valid].copy()
+    short[:, 7] = hits["t"][valid] * np.float32(1.0 - 4e-6)
+    assert (t.closest_hit(short)["t"] == FLT_MAX).all()
     t.close()
