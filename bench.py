@@ -22,12 +22,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, vendor peak
-# What bounds the traversal is not HBM (nodes and triangles of the 2^20-triangle scene are 112 MiB: they live in the
-# 256 MiB Infinity Cache and mostly in the L2s) but the rate at which a CU's vector memory pipeline takes 16-byte
-# loads whose 64 lanes go to 64 different cache lines. scripts/ubench/gather_mix measures that rate with the
-# kernel's own access shape (dependent random 64-byte records, four loads each, 77 % of them L2 hits, four waves
-# per SIMD like the kernel); bench.py runs it on the box when the binary is there, else it uses the figure measured for
-# profiles/r02_ubench_gather_mix_3waves.txt.
+L2_PEAK_GBS = 34500.0  # aggregate of the eight 4 MiB L2s (the figure of the MI355X guide this repository is built against)
+# HBM is not what the traversal runs against: nodes and triangles of the 2^20-triangle scene are 112 MiB and live in the
+# 256 MiB Infinity Cache and mostly in the L2s. The line therefore reports, beside the reference's algorithmic bytes over
+# the kernel time, (a) the bytes that the hardware counters saw beyond L2 and in front of it against the HBM and L2 peaks,
+# (b) how busy the counters found the units of a CU's vector memory pipeline and its SIMDs, and (c) the time each resource
+# would need for this launch's work alone. One of those resources is the rate at which a CU's vector memory pipeline takes
+# 16-byte loads whose 64 lanes go to 64 different cache lines: scripts/ubench/gather_mix measures it with the kernel's
+# access shape (dependent random 64-byte records, 77 % of them L2 hits, four waves per SIMD like the kernel); bench.py
+# runs it on the box when the binary is there, else it uses the figure of profiles/r02_ubench_gather_mix_3waves.txt.
 LANE_LOADS_PER_S_FALLBACK = 4 * 213.2e9
 MISS_RECORDS_PER_S_FALLBACK = 71.6e9
 SIMDS, VALU_CYCLES_PER_INSTRUCTION = 1024, 4
@@ -54,6 +57,7 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-host-buffers", action="store_true", help="skip the host-buffer (PCIe-inclusive) leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the primary-ray and shadow-ray rates")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL; gloo only to rehearse the launch on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses GPU 0")
@@ -113,17 +117,19 @@ def algorithmic_bytes(t, d_rays, layout):
     t.closest_hit_device(d_rays, d_hits, d_cnt)
     torch.cuda.synchronize(d_rays.device)
     work = t.profile_work()  # rays, inner pops, triangle tests, inner pops served from LDS
-    t.profile_end()
     s = d_cnt.sum(0, dtype=torch.int64).cpu().numpy()
     assert work[0] == n and work[1] == int(s[0]) and work[2] == int(s[1])
     per_tri = 52 + (4 if layout == "indexed" else 0)
     total = 48 * n + 56 * int(s[0]) + per_tri * int(s[1])
     hit_rate = float((d_hits[:, 0] != float(np.finfo(np.float32).max)).float().mean().item())
-    # 16-byte loads the lanes send to the vector cache: four per inner node not served from LDS, three per
-    # triangle, two per ray
-    lane_loads = 4 * (work[1] - work[3]) + 3 * work[2] + 2 * n
+    # 16-byte loads the lanes send to the vector cache: three per inner node not served from LDS (the twelve box
+    # planes), one more where the node's links are not implied by its index, three per triangle, two per ray
+    details = t.profile_details()
+    lane_loads = 3 * (work[1] - work[3]) + details["link_fetches"] + 3 * work[2] + 2 * n
+    t.profile_end()
     return dict(bytes=total, pops=float(s[0]) / n, tests=float(s[1]) / n, hit_rate=hit_rate, lane_loads=int(lane_loads),
-                lds_share=work[3] / max(work[1], 1), max_pops=int(d_cnt[:, 0].max().item()), hits=d_hits)
+                lds_share=work[3] / max(work[1], 1), max_pops=int(d_cnt[:, 0].max().item()), hits=d_hits,
+                link_fetch_share=details["link_fetches"] / max(work[1], 1))
 
 
 def cpu_baseline(args, w, gpu_hits):
@@ -156,6 +162,45 @@ def cpu_baseline(args, w, gpu_hits):
             "sample": "%d passes over the same %d bounce rays in %.1f s on %d threads, then every 16th ray on one thread in "
                       "%.1f s; CPU restatement of the reference tracer, OpenMP schedule(dynamic,1024), no per-ray stats "
                       "timers" % (passes, len(rays), dt, orc.max_threads(), dt1)}
+
+
+def other_ray_kinds(args, w, device, reps=10):
+    """Outside the timed headline: the other two ray populations of a frame on the same scene, each timed as whole
+    device calls (sort included where the library sorts) with the traversal-kernel time from HIP events beside it:
+    primary = closest_hit on this rank's jittered camera rays (what the reference's rt_bench times, driver/main.cpp:50-65),
+    shadow = any_hit from every primary hit towards a point light (gi/primary-hit.cpp:43-50)."""
+    import torch
+    from raytracing_amd import wavefront
+    t = w["tracer"]
+    dev = "cuda:%d" % device
+    npix = args.width * args.height
+    gen, kw, cam_pos, cam_dir, cam_up = WORKLOADS[args.workload]
+    cam_dir = np.asarray(cam_dir, np.float32) / np.float32(np.linalg.norm(cam_dir))
+    jitter = np.stack([wavefront.uniform01(np.arange(npix), 100, 0) - 0.5, wavefront.uniform01(np.arange(npix), 101, 0) - 0.5], 1).astype(np.float32)
+    d_primary = t.camera_rays_device(cam_dir, cam_pos, cam_up, 65.0, args.width, args.height, d_offsets=torch.from_numpy(jitter).to(dev))
+    d_hits = torch.empty((npix, 4), dtype=torch.float32, device=dev)
+    t.closest_hit_device(d_primary, d_hits)
+    lo, hi = w["pos"].min(0), w["pos"].max(0)
+    light = tuple(float(v) for v in (lo + hi) / 2 + (hi - lo) * np.array([0.15, 0.35, 0.2]))
+    d_shadow = t.shadow_rays_device(d_hits, light)
+    d_occ = torch.empty(npix, dtype=torch.uint8, device=dev)
+    out = {}
+    for name, call, n in (("primary", lambda: t.closest_hit_device(d_primary, d_hits), npix),
+                          ("shadow", lambda: t.any_hit_device(d_shadow, d_occ), npix)):
+        call()
+        t.profile_begin()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            call()
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        k_ms, launches = t.profile_end()
+        out[name] = {"value": round(reps * n / dt / 1e6, 2), "unit": "Mrays/s", "rays": int(n), "kernel_ms": round(k_ms / max(launches, 1), 4)}
+    out["shadow"]["occluded_share"] = round(float(d_occ.float().mean().item()), 4)
+    out["note"] = ("same scene, %dx%d: primary = closest_hit on jittered camera rays, shadow = any_hit from every primary hit "
+                   "towards a point light (rays of misses are empty); whole device calls, outside the timed headline" % (args.width, args.height))
+    return out
 
 
 def host_buffer_rates(t, rays, d_hits):
@@ -362,6 +407,8 @@ def main():
             },
             "roofline": roofline(args.workload, total_bytes, n, kernel_ms, alg, lane_rate, miss_rate, rate_source),
         }
+        if world == 1 and not args.no_extra:
+            out["extra"] = other_ray_kinds(args, w, device)
         # the drop-in form of the same call: rays and hits in host memory, PCIe both ways inside the call (never `value`)
         if not args.no_host_buffers and world == 1:
             out["host_buffer_path"] = host_buffer_rates(t, w["bounce"], d_hits)
@@ -446,16 +493,22 @@ def frame_mode(args, world, rank, device, grouped):
 
 
 def roofline(workload, total_bytes, n, kernel_ms, alg, lane_rate, miss_rate, rate_source):
-    """The ceiling that binds the dominant kernel and how close the kernel is to it.
+    """What the dominant kernel runs against, and how close it is.
 
-    `achieved` is the reference's algorithmic bytes per launch over the kernel time. `peak` is the same bytes over
-    the shortest time any resource allows for this launch's work; `frac` = achieved / peak = that time / kernel time.
-    Resources, each with its demand per launch and its capacity:
-      lane loads   16-byte loads of lanes going to different lines (counted by the kernel itself) / measured rate
-      valu         vector instructions x 4 cycles on 1024 SIMDs (counters under profiles/, only for this kernel)
-      beyond L2    L2 misses (counters under profiles/) / measured rate of random 64-byte fetches that miss L2
-      hbm          bytes beyond L2 (counters under profiles/) / 8 TB/s
-      chain        the longest ray's inner-node visits x the latency of one dependent fetch
+    `achieved` is the reference's algorithmic bytes per launch over the kernel time, measured here with HIP events on the
+    launch stream. Against the HBM peak that figure exceeds 1 (`algorithmic_bytes_over_hbm_peak`), because the tree lives
+    in the caches; so three kinds of figures stand beside it, each recomputable from the files under profiles/:
+      frac_hbm_traffic  bytes the counters saw beyond L2 per launch / kernel time / 8 TB/s
+      frac_l2           64-byte requests from the vector caches to L2 per launch x 64 / kernel time / 34.5 TB/s
+      pipeline_busy     busy and stall shares of the units of the vector memory pipeline (TA: texture addresser, TCP:
+                        vector cache, TD: data return) and of the SIMDs, as the hardware counters report them
+      frac              the largest of the times each resource needs for this launch's work alone / kernel time, with
+                        `bound` naming that resource and `peak` = the algorithmic bytes over that time. Resources:
+        lane loads   16-byte loads of lanes going to different lines (counted by the kernel itself) / measured rate
+        valu         vector instructions x 4 cycles on 1024 SIMDs
+        beyond L2    L2 misses / measured rate of random 64-byte fetches that miss L2
+        hbm          bytes beyond L2 / 8 TB/s
+        chain        the longest ray's inner-node visits x the latency of one dependent fetch
     The counters under profiles/ are used only if they were taken with this kernel source (hash) and workload."""
     t_kernel = kernel_ms * 1e-3
     times = {"lane_loads": alg["lane_loads"] / lane_rate, "chain": alg["max_pops"] * 355e-9}
@@ -470,13 +523,16 @@ def roofline(workload, total_bytes, n, kernel_ms, alg, lane_rate, miss_rate, rat
              "chain": "latency of the longest ray's chain of dependent fetches"}
     achieved = total_bytes / t_kernel / 1e9
     frac = times[bound] / t_kernel
-    return {
+    out = {
         "bound": names[bound],
         "achieved": round(achieved, 1),
         "peak": round(achieved / frac, 1),
         "unit": "GB/s",
         "frac": round(frac, 4),
         "traffic": pmc["bytes_beyond_l2"] if pmc else None,
+        "frac_hbm_traffic": round(pmc["bytes_beyond_l2"] / t_kernel / (HBM_PEAK_GBS * 1e9), 4) if pmc else None,
+        "frac_l2": round(pmc["tcp_to_l2_read_requests"] * 64 / t_kernel / (L2_PEAK_GBS * 1e9), 4) if pmc else None,
+        "pipeline_busy": pmc.get("busy") if pmc else None,
         "kernel": "rtgi_dev::trace_kernel<closest_hit> (ray sort and counter reset excluded)",
         "kernel_ms": round(kernel_ms, 4),
         "algorithmic_bytes_per_launch": int(total_bytes),
@@ -487,8 +543,13 @@ def roofline(workload, total_bytes, n, kernel_ms, alg, lane_rate, miss_rate, rat
         "lane_load_rate_per_s": lane_rate,
         "lane_load_rate_source": rate_source,
         "inner_visits_served_from_lds": round(alg["lds_share"], 4),
-        "counters": ("profiles/traffic.json" if pmc else "none for kernel source %s: traffic, valu, beyond_l2 and hbm not priced" % kernel_source_hash()),
+        "inner_visits_that_fetch_links": round(alg["link_fetch_share"], 4),
+        "counters": ("profiles/traffic.json" if pmc else "none for kernel source %s: traffic, fractions, busy shares, valu, beyond_l2 and hbm not priced" % kernel_source_hash()),
     }
+    if pmc:
+        out["waves"] = {k: pmc[k] for k in ("wave_cycles_executing", "wave_cycles_waiting_for_issue", "wave_cycles_waiting_for_anything",
+                                            "l2_request_latency_cycles") if pmc.get(k) is not None}
+    return out
 
 
 def _measured_counters(workload):

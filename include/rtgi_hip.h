@@ -343,11 +343,16 @@ int rtgi_hip_profile_end(rtgi_hip_tracer *h, double *kernel_ms_total, uint32_t *
  * from the kernel's copy of the top of the tree in LDS instead of the vector cache. Waits for the GPU. */
 int rtgi_hip_profile_work(rtgi_hip_tracer *h, uint64_t out[4]);
 
-/* The stack of the traversal (the reference keeps 25 slots per ray and does not check them, bvh2.cpp:419,469): here as
- * many pending nodes per ray as the tree is deep, the first *lds_levels of them in LDS and, for deeper trees,
- * *spill_levels more in a global area. *pushes = the pushes of the counting launches since the last profile_begin
- * that went to the global area (0 for a tree that fits in LDS); waits for the GPU. Any pointer may be NULL. */
-int rtgi_hip_profile_spills(rtgi_hip_tracer *h, uint64_t *pushes, uint32_t *lds_levels, uint32_t *spill_levels);
+/* More about the counting launches since the last profile_begin, and about the handle's stack (any pointer may be NULL;
+ * waits for the GPU if a count is asked for):
+ *   *lds_levels / *spill_levels: the traversal keeps as many pending nodes per ray as the tree is deep (the reference has
+ *     25 slots per ray and does not check them, bvh2.cpp:419,469): the first *lds_levels in LDS and, for deeper trees,
+ *     *spill_levels more in a global area;
+ *   *spill_pushes: pushes that went to the global area (0 for a tree that fits in LDS);
+ *   *link_fetches: inner-node visits that had to fetch the node's two links from memory. The levels at the top of the tree
+ *     that hold inner nodes only are numbered like a heap, so most visits compute the children's indices instead. */
+int rtgi_hip_profile_details(rtgi_hip_tracer *h, uint64_t *spill_pushes, uint64_t *link_fetches, uint32_t *lds_levels,
+                             uint32_t *spill_levels);
 
 /* Text of the last error on this handle (h may be NULL: last error of a failed create). */
 const char *rtgi_hip_last_error(const rtgi_hip_tracer *h);

@@ -1825,20 +1825,21 @@ int rtgi_hip_profile_work(rtgi_hip_tracer *h, uint64_t out[4]) {
 	return RTGI_OK;
 }
 
-int rtgi_hip_profile_spills(rtgi_hip_tracer *h, uint64_t *pushes, uint32_t *lds_levels, uint32_t *spill_levels) {
+int rtgi_hip_profile_details(rtgi_hip_tracer *h, uint64_t *spill_pushes, uint64_t *link_fetches, uint32_t *lds_levels, uint32_t *spill_levels) {
 	if (!h) return RTGI_ERR_INVALID;
 	if (h->device < 0) return fail(h, RTGI_ERR_DEVICE, "host-only handle: needs a GPU");
 	if (lds_levels) *lds_levels = h->stack_levels;
 	if (spill_levels) *spill_levels = h->spill_levels;
-	if (!pushes) return RTGI_OK;
-	*pushes = 0;
-	if (!h->d_totals) return RTGI_OK;  // (no profile_begin yet: nothing has been counted)
+	if (spill_pushes) *spill_pushes = 0;
+	if (link_fetches) *link_fetches = 0;
+	if ((!spill_pushes && !link_fetches) || !h->d_totals) return RTGI_OK;  // (no profile_begin yet: nothing has been counted)
 	DeviceScope device_scope(h->device);
 	HIP_TRY(h, device_scope.status);
 	HIP_TRY(h, hipDeviceSynchronize());
-	unsigned long long v = 0;
-	HIP_TRY(h, hipMemcpy(&v, h->d_totals + 4, sizeof(v), hipMemcpyDeviceToHost));
-	*pushes = v;
+	unsigned long long v[2] = {0, 0};
+	HIP_TRY(h, hipMemcpy(v, h->d_totals + 4, sizeof(v), hipMemcpyDeviceToHost));
+	if (spill_pushes) *spill_pushes = v[0];
+	if (link_fetches) *link_fetches = v[1];
 	return RTGI_OK;
 }
 

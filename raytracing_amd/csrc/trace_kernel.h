@@ -66,7 +66,7 @@ struct TraceArgs {
 	float4 *hits;           // closest_hit output
 	uint8_t *occluded;      // any_hit output
 	uint32_t *counts;       // optional: 2 per ray
-	unsigned long long *totals;  // optional, counting kernels only: five sums over the launch, see the end of the kernel
+	unsigned long long *totals;  // optional, counting kernels only: six sums over the launch, see the end of the kernel
 	int32_t *spill;         // DEEP only: [level - stack_levels][global lane]
 	uint32_t *ray_counter;  // n_segments counters, COUNTER_STRIDE words apart (one cache line each)
 	uint32_t n_rays;
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void trace_kernel(TraceArgs 
 	const float4 *my_rays = a.rays;
 	void *my_out = nullptr;     // MIXED: where this lane's result goes
 	uint32_t n_inner = 0, n_tri = 0, n_top = 0;
-	unsigned long long sum_rays = 0, sum_inner = 0, sum_tri = 0, sum_top = 0, sum_spill = 0;  // COUNT: over all rays of this lane
+	unsigned long long sum_rays = 0, sum_inner = 0, sum_tri = 0, sum_top = 0, sum_spill = 0, sum_links = 0;  // COUNT: over all rays of this lane
 	int32_t cur = IDLE;
 	int sp = 0;          // pending entries in memory (the next node to visit is `cur`, in a register)
 	bool plain = true;   // no NaN can arise in this ray's slab tests
@@ -345,7 +345,8 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void trace_kernel(TraceArgs 
 				hr = slab(ax.y, bx.y, ay.y, by.y, az.y, bz.y, dr);
 			}
 			// bvh2.cpp:434-446: both hit -> nearer first, the right child on a tie, the other one pending
-			left_first = hl && ((dl < dr) || !hr);
+			// (& and | on purpose: lane masks combined by scalar instructions instead of branches)
+			left_first = hl & ((dl < dr) | !hr);
 		};
 		// the twelve box planes of inner node `cur` (and its links, where they are not implied), from the copy in LDS or
 		// from memory. (All loads from memory go out before the first LDS read, which has to wait for them: the compiler
@@ -356,7 +357,10 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void trace_kernel(TraceArgs 
 				q0 = __builtin_amdgcn_raw_buffer_load_b128(node_rsrc, voff, 0, 0);
 				q1 = __builtin_amdgcn_raw_buffer_load_b128(node_rsrc, voff + 16, 0, 0);
 				q2 = __builtin_amdgcn_raw_buffer_load_b128(node_rsrc, voff + 32, 0, 0);
-				if (with_links) links = __builtin_amdgcn_raw_buffer_load_b64(node_rsrc, voff + 48, 0, 0);
+				if (with_links) {
+					links = __builtin_amdgcn_raw_buffer_load_b64(node_rsrc, voff + 48, 0, 0);
+					if (COUNT) ++sum_links;
+				}
 			} else {
 				const u32x4 *rec = reinterpret_cast<const u32x4 *>(s_mem + top_offset + __umul24((uint32_t)cur, 48u));
 				q0 = rec[0], q1 = rec[1], q2 = rec[2];
@@ -369,9 +373,9 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void trace_kernel(TraceArgs 
 		// lanes have left it (reached a leaf or finished their ray), or nobody is left -----------------------------------
 		auto inner_phase = [&](auto plain_tag) {
 			const int keep_going = max(0, n_busy - leave);
-			for (;;) {
+			// (the count of lanes on inner nodes is wave-uniform and carried from the end of one iteration to the next)
+			for (unsigned long long on_inner = __ballot(cur >= 0); (int)__popcll(on_inner) > keep_going; on_inner = __ballot(cur >= 0)) {
 				const bool at_inner = cur >= 0;
-				if ((int)__popcll(__ballot(at_inner)) <= keep_going) break;
 #ifdef RTGI_DIAG
 				if (more) ++dg_it_more, dg_ln_more += __popcll(__ballot(at_inner));
 				else ++dg_it_drain, dg_ln_drain += __popcll(__ballot(at_inner));
@@ -446,9 +450,10 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void trace_kernel(TraceArgs 
 				advance();
 		}
 	}
-	if (COUNT && a.totals) {  // rays, inner nodes popped, triangles tested, inner nodes read from the copy in LDS, pushes beyond the LDS stack
-		unsigned long long v[5] = {sum_rays, sum_inner, sum_tri, sum_top, sum_spill};
-		for (int k = 0; k < 5; ++k) {
+	if (COUNT && a.totals) {  // rays, inner nodes popped, triangles tested, inner nodes read from the copy in LDS, pushes beyond the
+		// LDS stack, links fetched from memory
+		unsigned long long v[6] = {sum_rays, sum_inner, sum_tri, sum_top, sum_spill, sum_links};
+		for (int k = 0; k < 6; ++k) {
 			for (int step = 32; step > 0; step >>= 1) v[k] += __shfl_xor(v[k], step);
 			if (lane == 0) atomicAdd(a.totals + k, v[k]);
 		}

@@ -34,7 +34,7 @@ EXPORTS = [
     "rtgi_hip_bounce_rays_keyed_device", "rtgi_hip_path_begin_device", "rtgi_hip_path_add_device", "rtgi_hip_path_extend_device",
     "rtgi_hip_framebuffer_scatter_device", "rtgi_hip_framebuffer_sums_device", "rtgi_hip_framebuffer_accumulate_device", "rtgi_hip_shadow_rays_device", "rtgi_hip_bounce_rays_device", "rtgi_hip_set_shading",
     "rtgi_hip_shade_primary_device", "rtgi_hip_shade_local_device", "rtgi_hip_set_materials", "rtgi_hip_set_textures", "rtgi_hip_shade_local_brdf_device", "rtgi_hip_framebuffer_add_device",
-    "rtgi_hip_framebuffer_rgb8_device", "rtgi_hip_profile_begin", "rtgi_hip_profile_end", "rtgi_hip_profile_work", "rtgi_hip_profile_spills",
+    "rtgi_hip_framebuffer_rgb8_device", "rtgi_hip_profile_begin", "rtgi_hip_profile_end", "rtgi_hip_profile_work", "rtgi_hip_profile_details",
     "rtgi_hip_last_error",
 ]
 
@@ -116,7 +116,7 @@ def lib():
         L.rtgi_hip_profile_begin.argtypes = [vp]
         L.rtgi_hip_profile_end.argtypes = [vp, vp, vp]
         L.rtgi_hip_profile_work.argtypes = [vp, vp]
-        L.rtgi_hip_profile_spills.argtypes = [vp, vp, vp, vp]
+        L.rtgi_hip_profile_details.argtypes = [vp, vp, vp, vp, vp]
         L.rtgi_hip_last_error.argtypes = [vp]
         L.rtgi_hip_last_error.restype = cp
         _lib = L
@@ -403,12 +403,12 @@ class HipBvhTracer:
         self._check(lib().rtgi_hip_profile_work(self._h, out))
         return tuple(int(v) for v in out)
 
-    def profile_spills(self):
-        """(pushes of the counting launches since profile_begin that went beyond the LDS part of the stack, stack levels
-        kept in LDS, levels in the global spill area)."""
-        pushes, lds, spill = C.c_uint64(0), C.c_uint32(0), C.c_uint32(0)
-        self._check(lib().rtgi_hip_profile_spills(self._h, C.byref(pushes), C.byref(lds), C.byref(spill)))
-        return pushes.value, lds.value, spill.value
+    def profile_details(self):
+        """dict(spill_pushes, link_fetches: of the counting launches since profile_begin; lds_levels, spill_levels: how the
+        stack is divided between LDS and the global spill area)."""
+        pushes, links, lds, spill = C.c_uint64(0), C.c_uint64(0), C.c_uint32(0), C.c_uint32(0)
+        self._check(lib().rtgi_hip_profile_details(self._h, C.byref(pushes), C.byref(links), C.byref(lds), C.byref(spill)))
+        return dict(spill_pushes=pushes.value, link_fetches=links.value, lds_levels=lds.value, spill_levels=spill.value)
 
     def _check_device_args(self, d_rays, d_out, out_width, d_counts):
         import torch

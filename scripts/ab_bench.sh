@@ -7,7 +7,7 @@ for round in 1 2; do
 		lib=${spec%%:*}
 		envs=""
 		if [ "$spec" != "$lib" ]; then envs=$(echo "${spec#*:}" | tr ',' ' '); fi
-		env RTGI_HIP_LIB=$lib $envs timeout -k 10 200 python3 bench.py --steps 20 --warmup 3 --no-cpu --no-host-buffers $BENCH_ARGS 2>/dev/null |
+		env RTGI_HIP_LIB=$lib $envs timeout -k 10 200 python3 bench.py --steps 20 --warmup 3 --no-cpu --no-host-buffers --no-extra $BENCH_ARGS 2>/dev/null |
 			python3 -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('%-60s %8.2f Mrays/s  step %.4f ms  kernel %.4f ms  lds %.4f' % ('$spec', d['value'], d['ms_per_step'], r['kernel_ms'], r['inner_visits_served_from_lds']))"
 	done
 done

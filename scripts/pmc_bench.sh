@@ -13,7 +13,7 @@ BENCH_ARGS="$*"
 run_pass() {
 	name=$1; shift
 	if [ -n "$PASSES" ] && ! echo " $PASSES " | grep -q " $name "; then return 0; fi
-	timeout -s KILL 180 rocprofv3 --pmc "$@" --output-format csv -d $out/$name -o pmc -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-host-buffers $BENCH_ARGS > $out/$name.json 2> $out/$name.err
+	timeout -s KILL 180 rocprofv3 --pmc "$@" --output-format csv -d $out/$name -o pmc -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-host-buffers --no-extra $BENCH_ARGS > $out/$name.json 2> $out/$name.err
 	echo "pass $name done"
 }
 # instruction mix, occupancy, waiting

@@ -44,6 +44,16 @@ def main():
     pmc_dir, workload = sys.argv[1], sys.argv[2]
     c = per_launch(pmc_dir)
     ns = [v for k, v in c.items() if k.startswith("_ns:")]
+    cus, simds, xcds = 256, 1024, 8
+
+    def per(name, unit_count, elapsed_pass):
+        """Counter summed over its units / (units x cycles of the launch in the pass that collected it)."""
+        if name not in c:
+            return None
+        cycles = c["_ns:" + elapsed_pass] * clock_ghz  # ns x GHz
+        return round(c[name] / unit_count / cycles, 4)
+
+    clock_ghz = c["GRBM_GUI_ACTIVE"] / xcds / c["_ns:tcp"]  # GRBM_GUI_ACTIVE sums the 8 XCDs; timestamps are in ns
     entry = {
         "kernel_source": kernel_source_hash(),
         "bytes_beyond_l2": int((c["FETCH_SIZE"] * 1.20 + c["WRITE_SIZE"]) * 1024),
@@ -54,9 +64,31 @@ def main():
         "valu_instructions": int(c["SQ_INSTS_VALU"]),
         "salu_instructions": int(c["SQ_INSTS_SALU"]),
         "vmem_read_instructions": int(c["SQ_INSTS_VMEM_RD"]),
-        # GRBM_GUI_ACTIVE sums the 8 XCDs; timestamps are in ns
-        "clock_ghz": round(c["GRBM_GUI_ACTIVE"] / 8.0 / c["_ns:tcp"], 3),
+        "lds_instructions": int(c["SQ_INSTS_LDS"]),
+        "clock_ghz": round(clock_ghz, 3),
         "kernel_ms_under_profiler": round(sum(ns) / len(ns) * 1e-6, 4),
+        # busy and stall shares: cycles counted by a unit, summed over the units of that kind, over units x elapsed
+        # cycles of the launch in the same pass (256 TA / TCP / TD, one each per CU; 1024 SIMDs; SQ_* activity
+        # counters tick once per 4 cycles)
+        "busy": {k: v for k, v in {
+            "ta_busy": per("TA_TA_BUSY_sum", cus, "ta1"),
+            "ta_addr_stalled_by_tcp": per("TA_ADDR_STALLED_BY_TC_CYCLES_sum", cus, "ta1"),
+            "ta_data_stalled_by_tcp": per("TA_DATA_STALLED_BY_TC_CYCLES_sum", cus, "ta2"),
+            "ta_buffer_instruction_cycles": per("TA_BUFFER_TOTAL_CYCLES_sum", cus, "ta3"),
+            "td_busy": per("TD_TD_BUSY_sum", cus, "td1"),
+            "td_stalled_by_tcp": per("TD_TC_STALL_sum", cus, "td1"),
+            "tcp_clock_on": per("TCP_GATE_EN1_sum", cus, "tcp1"),
+            "tcp_pending_stall": per("TCP_PENDING_STALL_CYCLES_sum", cus, "tcp1"),
+            "tcp_read_tagconflict_stall": per("TCP_READ_TAGCONFLICT_STALL_CYCLES_sum", cus, "tcp2"),
+            "tcp_tag_lookups_per_cycle": per("TCP_TOTAL_CACHE_ACCESSES_sum", cus, "tcp"),
+            "valu_busy": (lambda v: None if v is None else round(4 * v, 4))(per("SQ_ACTIVE_INST_VALU", simds, "sq1")),
+            "salu_busy": (lambda v: None if v is None else round(4 * v, 4))(per("SQ_ACTIVE_INST_SCA", simds, "sq3")),
+        }.items() if v is not None},
+        "ta_buffer_wavefronts": int(c.get("TA_BUFFER_WAVEFRONTS_sum", 0)),
+        "wave_cycles_waiting_for_anything": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 4) if "SQ_WAIT_ANY" in c else None,
+        "wave_cycles_waiting_for_issue": round(c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"], 4) if "SQ_WAIT_INST_ANY" in c else None,
+        "wave_cycles_executing": round(c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], 4) if "SQ_ACTIVE_INST_ANY" in c else None,
+        "l2_request_latency_cycles": round(c["TCP_TCC_READ_REQ_LATENCY_sum"] / c["TCP_TCC_READ_REQ_sum"], 1) if "TCP_TCC_READ_REQ_LATENCY_sum" in c else None,
         "source": pmc_dir,
     }
     path = os.path.join(ROOT, "profiles", "traffic.json")
@@ -70,7 +102,8 @@ def main():
     data["_note"] = ("per launch of trace_kernel<closest_hit> on the workload's bounce batch, separate rocprofv3 --pmc passes "
                      "(scripts/pmc_bench.sh, scripts/pmc_to_traffic.py); bytes_beyond_l2 = (FETCH_SIZE x 1.20 + WRITE_SIZE) x 1024, "
                      "1.20 = calibration of FETCH_SIZE on random 64-byte gathers (profiles/r01b_fetch_size_calibration.txt); "
-                     "Infinity Cache hits are included in it")
+                     "Infinity Cache hits are included in it; busy.*: counter / (units x elapsed cycles of the launch in the "
+                     "pass that collected it), elapsed cycles = launch duration x clock_ghz")
     data = {k: data[k] for k in sorted(data, key=lambda k: (k.startswith("_"), k))}
     with open(path, "w") as f:
         json.dump(data, f, indent=1)

@@ -166,7 +166,7 @@ def test_config5_deep_stack_scene_spills_at_4m_triangles():
     t = tracer.HipBvhTracer(layout="indexed")
     assert t.interprete("bvh", "sm")
     t.build(pos, tri)
-    _, lds_levels, spill_levels = t.profile_spills()
+    lds_levels, spill_levels = t.profile_details()["lds_levels"], t.profile_details()["spill_levels"]
     assert t.depth > 40 and spill_levels > 0 and lds_levels + spill_levels == t.depth
     n = 1 << 20
     rays = scenes.stadium_rays(n, seed=3, sheets=40)
@@ -185,7 +185,7 @@ def test_config5_deep_stack_scene_spills_at_4m_triangles():
     t.closest_hit_device(d_rays, d_hits2, d_cnt)
     torch.cuda.synchronize()
     work = t.profile_work()
-    pushes, _, _ = t.profile_spills()
+    pushes = t.profile_details()["spill_pushes"]
     t.profile_end()
     assert torch.equal(d_hits2, d_hits)
     o = orc.Bbvh(pos, tri, layout="indexed", split="sm")
