@@ -133,11 +133,19 @@ int rtgi_hip_get_triangle_order(const rtgi_hip_tracer *h, uint32_t *out);
  * Synchronous. Batches of more than 256 rays go through the GPU in chunks on three streams (rays of chunk k + 1 on
  * their way up while chunk k is traced; the kernel stores hit records straight into page-locked host memory).
  * Buffers in ordinary memory are staged through page-locked slots by a few copying threads; buffers from
- * rtgi_hip_host_alloc / rtgi_hip_host_register are used in place. */
+ * rtgi_hip_host_alloc / rtgi_hip_host_register are used in place, and batches of 2^19 rays and more in such buffers
+ * are traced by ONE launch that begins when the first eighth of the batch has arrived and takes up the rest as it
+ * comes (one tail instead of one per chunk; rtgi_hip_host_path_stats counts these launches). */
 int rtgi_hip_closest_hit(rtgi_hip_tracer *h, const rtgi_ray *rays, uint32_t n, rtgi_hit *hits);
 
 /* compute_any_hit(), wavefront-rt.h:74-80 / bvh2.cpp:465-501: occluded[i] = any_hit(rays[i]) as 0/1. */
 int rtgi_hip_any_hit(rtgi_hip_tracer *h, const rtgi_ray *rays, uint32_t n, uint8_t *occluded);
+
+/* How the page-locked batches of the two calls above went (no counterpart in the reference): *one_launch = batches traced
+ * by one launch beside their own upload; *gave_up = those among them whose launch waited in vain for a part of the
+ * batch (its upload or sort found no room on the GPU beside the launch, e.g. while other processes use it) and which
+ * were then traced again chunk by chunk: the results are the same, the time is lost. Either pointer may be NULL. */
+int rtgi_hip_host_path_stats(const rtgi_hip_tracer *h, uint64_t *one_launch, uint64_t *gave_up);
 
 /* Page-locked host memory for the host-buffer entry points above (no counterpart in the reference). Rays and
  * results in ordinary (pageable) memory are copied through a staging area by the HIP runtime; page-locked memory

@@ -143,8 +143,11 @@ private:
 // the results of chunk k - 1 go down. Memory that is not page-locked is staged through page-locked slots.
 struct HostPipe {
 	static constexpr int SLOTS = 3;
-	hipStream_t up = nullptr, run = nullptr, down = nullptr;
+	hipStream_t up = nullptr, run = nullptr, down = nullptr, aux = nullptr;  // aux: sorts that run beside a traversal launch
 	hipEvent_t came_up[SLOTS] = {}, traced[SLOTS] = {}, went_down[SLOTS] = {};
+	hipEvent_t chunk_up[rtgi_dev::MAX_CHUNKS] = {}, begun = nullptr, first_ready = nullptr, aux_done = nullptr;
+	// RTGI_HIP_STREAM_TIMES: when each chunk of a streamed batch was up and sorted, and when its launch ended, on stderr
+	hipEvent_t clock_begin = nullptr, clock_up[rtgi_dev::MAX_CHUNKS] = {}, clock_ready[rtgi_dev::MAX_CHUNKS] = {}, clock_end = nullptr;
 	void *slot_rays[SLOTS] = {}, *slot_out[SLOTS] = {};
 	size_t slot_rays_cap = 0;  // rays per slot
 	CopyPool pool;
@@ -214,6 +217,16 @@ struct rtgi_hip_tracer {
 	// small host batches (the per-ray interface): pinned host memory that the kernel reads and writes directly
 	void *pinned = nullptr, *d_pinned = nullptr;
 	HostPipe *pipe = nullptr;
+	// page-locked host batches in ONE launch that takes up the later chunks as their upload and sort complete
+	bool host_streamed = true;
+	uint32_t stream_min = 1u << 19;    // batches of at least this many rays
+	uint32_t stream_lds_bytes = 96u << 10;  // the launch leaves LDS free for the sort kernels that run beside it
+	uint32_t stream_wait_ticks = 2000000;  // how long a wave waits for a chunk before the launch gives up (100 MHz: 20 ms)
+	uint64_t streamed_calls = 0, streamed_gave_up = 0;
+	uint32_t *d_stream_ctl = nullptr;  // ray counters of the chunks | octant bounds of the chunks | chunks_ready | gave_up
+	// where the chunks end, as shares of the batch: the first one short (the launch begins when it is sorted), the
+	// following ones as large as the traversal of their predecessors takes the next upload and sort to complete
+	float stream_parts[8] = {0.12f, 0.40f, 1.0f, 0, 0, 0, 0, 0};
 	uint32_t host_chunk = 768u << 10;  // rays per chunk of a large host batch (every chunk's launch ends in its own tail)
 	uint32_t host_lead = 256u << 10, host_lead_min = 192u << 10;  // the short first chunk: at most / batches of twice this have one
 	bool host_direct = true;           // closest_hit on host batches: the kernel writes the hit records to host memory itself
@@ -298,6 +311,19 @@ void read_tunables(rtgi_hip_tracer *h) {
 	h->host_chunk = (uint32_t)number("RTGI_HIP_HOST_CHUNK", 1 << 16, 1 << 30, (int)h->host_chunk);
 	h->host_lead = (uint32_t)number("RTGI_HIP_HOST_LEAD", 0, 1 << 30, (int)h->host_lead);
 	h->host_direct = number("RTGI_HIP_HOST_DIRECT", 0, 1, 1) != 0;
+	h->host_streamed = number("RTGI_HIP_HOST_STREAMED", 0, 1, 1) != 0;
+	h->stream_min = (uint32_t)number("RTGI_HIP_STREAM_MIN", 1 << 16, 1 << 30, (int)h->stream_min);
+	h->stream_lds_bytes = (uint32_t)number("RTGI_HIP_STREAM_LDS_KIB", 16, 160, (int)(h->stream_lds_bytes >> 10)) << 10;
+	h->stream_wait_ticks = (uint32_t)number("RTGI_HIP_STREAM_WAIT_TICKS", 1, 1 << 30, (int)h->stream_wait_ticks);
+	if (const char *e = getenv("RTGI_HIP_STREAM_PARTS")) {  // e.g. "0.2,0.5,1"
+		int c = 0;
+		for (const char *q = e; *q && c < 8; ++c) {
+			h->stream_parts[c] = (float)atof(q);
+			while (*q && *q != ',') ++q;
+			if (*q == ',') ++q;
+		}
+		for (; c < 8; ++c) h->stream_parts[c] = 0.0f;
+	}
 }
 
 // The GPU form of h->tree (already flattened: `flat`) goes to the handle's GPU, together with what the launches derive
@@ -495,6 +521,7 @@ int sort_rays(rtgi_hip_tracer *h, const BatchView *batches, uint32_t n_batches, 
 	}
 	k.inv_diagonal = diag2 > 0.0f ? 1.0f / std::sqrt(diag2) : 0.0f;
 	k.first = 0;
+	k.index_base = 0;
 	for (uint32_t b = 0; b < n_batches; ++b) {
 		k.rays = (const float4 *)batches[b].rays;
 		k.n = batches[b].n;
@@ -745,6 +772,19 @@ int ensure_pipe(rtgi_hip_tracer *h) {
 	HIP_TRY(h, hipStreamCreateWithFlags(&p->up, hipStreamNonBlocking));
 	HIP_TRY(h, hipStreamCreateWithFlags(&p->run, hipStreamNonBlocking));
 	HIP_TRY(h, hipStreamCreateWithFlags(&p->down, hipStreamNonBlocking));
+	HIP_TRY(h, hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking));
+	for (int i = 0; i < rtgi_dev::MAX_CHUNKS; ++i) HIP_TRY(h, hipEventCreateWithFlags(&p->chunk_up[i], hipEventDisableTiming));
+	HIP_TRY(h, hipEventCreateWithFlags(&p->first_ready, hipEventDisableTiming));
+	HIP_TRY(h, hipEventCreateWithFlags(&p->aux_done, hipEventDisableTiming));
+	if (getenv("RTGI_HIP_STREAM_TIMES")) {
+		HIP_TRY(h, hipEventCreate(&p->clock_begin));
+		HIP_TRY(h, hipEventCreate(&p->clock_end));
+		for (int i = 0; i < rtgi_dev::MAX_CHUNKS; ++i) {
+			HIP_TRY(h, hipEventCreate(&p->clock_up[i]));
+			HIP_TRY(h, hipEventCreate(&p->clock_ready[i]));
+		}
+	}
+	HIP_TRY(h, hipEventCreateWithFlags(&p->begun, hipEventDisableTiming));
 	for (int i = 0; i < HostPipe::SLOTS; ++i) {
 		HIP_TRY(h, hipEventCreateWithFlags(&p->came_up[i], hipEventDisableTiming));
 		HIP_TRY(h, hipEventCreateWithFlags(&p->traced[i], hipEventDisableTiming));
@@ -781,6 +821,168 @@ bool is_page_locked(const void *ptr) {
 	return attr.type == hipMemoryTypeHost;
 }
 
+// A page-locked host batch in ONE traversal launch. The batch goes up in a few chunks of growing size; each chunk is
+// keyed and sorted on its own as soon as it has arrived (on a stream of its own, beside the traversal, which leaves
+// LDS and wave slots free for those kernels), and the launch, begun when the first chunk is ready, takes up the later
+// ones as a word in GPU memory announces them: one tail for the whole batch instead of one per chunk, and the upload
+// hidden behind the traversal. If the launch ever waits in vain for a chunk (the other kernels found no place to run)
+// it gives up and says so; *fell_back then tells the caller to trace the batch the ordinary way.
+// closest_hit stores its records straight into the (page-locked) destination; any_hit's bytes come down in one copy.
+template <bool ANY>
+int trace_host_streamed(rtgi_hip_tracer *h, const rtgi_ray *rays, uint32_t n, void *out, bool sort, bool *fell_back) {
+	using namespace rtgi_dev;
+	*fell_back = true;
+	HostPipe &p = *h->pipe;
+	constexpr uint32_t CTL_COUNTERS = MAX_CHUNKS * 8 * COUNTER_STRIDE, CTL_BOUNDS = CTL_COUNTERS, CTL_READY = CTL_BOUNDS + MAX_CHUNKS * 16,
+	                   CTL_GAVE_UP = CTL_READY + 1, CTL_WORDS = CTL_READY + 16;
+	if (!h->d_stream_ctl) HIP_TRY(h, hipMalloc((void **)&h->d_stream_ctl, CTL_WORDS * sizeof(uint32_t)));
+	void *d_out_host = nullptr;  // the destination as the GPU sees it
+	if (!ANY && (hipHostGetDevicePointer(&d_out_host, out, 0) != hipSuccess || !d_out_host)) {
+		(void)hipGetLastError();
+		return RTGI_OK;  // (not mapped into the GPU's address space: the ordinary way)
+	}
+	// chunks: a short first one to get the launch going, the rest in growing parts (the upload outruns the traversal)
+	uint32_t n_chunks = 0;
+	uint32_t ends[MAX_CHUNKS];
+	for (int c = 0; c < MAX_CHUNKS && h->stream_parts[c] > 0.0f; ++c) {
+		const uint32_t end = h->stream_parts[c] >= 1.0f ? n : (uint32_t)((double)n * h->stream_parts[c]) & ~63u;
+		if (end > (n_chunks ? ends[n_chunks - 1] : 0u)) ends[n_chunks++] = end;
+		if (end == n) break;
+	}
+	if (n_chunks == 0 || ends[n_chunks - 1] != n) {
+		if (n_chunks == MAX_CHUNKS) --n_chunks;
+		ends[n_chunks++] = n;
+	}
+	Scratch sc;
+	if (int rc = handle_scratch(h, n, sort, sc)) return rc;
+	const size_t cap = sc.sort_cap;
+	if (sort) {  // the sort's own scratch must hold for every chunk's size (the library picks its algorithm by size)
+		size_t need = 0;
+		for (uint32_t c = 0; c < n_chunks; ++c) {
+			size_t temp = 0;
+			hipcub::DoubleBuffer<uint32_t> keys(sc.sort, sc.sort + cap), index(sc.sort + 2 * cap, sc.sort + 3 * cap);
+			HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(nullptr, temp, keys, index, (int)(ends[c] - (c ? ends[c - 1] : 0)), 0, KEY_BITS, nullptr));
+			need = std::max(need, temp);
+		}
+		if (need > h->sort_temp_bytes) {
+			HIP_TRY(h, hipDeviceSynchronize());
+			if (h->d_sort_temp) (void)hipFree(h->d_sort_temp);
+			h->d_sort_temp = nullptr;
+			h->sort_temp_bytes = 0;
+			HIP_TRY(h, hipMalloc(&h->d_sort_temp, need + need / 4 + 256));
+			h->sort_temp_bytes = need + need / 4 + 256;
+			sc.sort_temp = h->d_sort_temp;
+			sc.sort_temp_bytes = h->sort_temp_bytes;
+		}
+	}
+	ScratchTurn turn{h, p.run};
+	if (int rc = turn.begin()) return rc;
+	HIP_TRY(h, hipMemsetAsync(h->d_stream_ctl, 0, CTL_WORDS * sizeof(uint32_t), p.run));
+	HIP_TRY(h, hipEventRecord(p.begun, p.run));  // the scratch memory is this call's from here on
+	const bool clocked = p.clock_begin != nullptr;
+	if (clocked) (void)hipEventRecord(p.clock_begin, p.run);
+	HIP_TRY(h, hipStreamWaitEvent(p.aux, p.begun, 0));
+	TraceArgs a;
+	memset(&a, 0, sizeof(a));
+	rtgi_ray *d_rays = (rtgi_ray *)h->d_stage_rays;
+	KeyArgs k;
+	float diag2 = 0.0f;
+	for (int c = 0; c < 3; ++c) {
+		k.lo[c] = h->scene_lo[c], k.hi[c] = h->scene_hi[c], k.inv_extent[c] = h->scene_inv_extent[c];
+		diag2 += (h->scene_hi[c] - h->scene_lo[c]) * (h->scene_hi[c] - h->scene_lo[c]);
+	}
+	k.inv_diagonal = diag2 > 0.0f ? 1.0f / std::sqrt(diag2) : 0.0f;
+	for (uint32_t c = 0; c < n_chunks; ++c) {
+		const uint32_t begin = c ? ends[c - 1] : 0, count = ends[c] - begin;
+		HIP_TRY(h, hipMemcpyAsync(d_rays + begin, rays + begin, (size_t)count * sizeof(rtgi_ray), hipMemcpyHostToDevice, p.up));
+		HIP_TRY(h, hipEventRecord(p.chunk_up[c], p.up));
+		HIP_TRY(h, hipStreamWaitEvent(p.aux, p.chunk_up[c], 0));
+		a.chunk_end[c] = ends[c];
+		if (sort) {
+			// this chunk's part of the four sort arrays; which of each pair holds the result is known when the call returns
+			hipcub::DoubleBuffer<uint32_t> keys(sc.sort + begin, sc.sort + cap + begin), index(sc.sort + 2 * cap + begin, sc.sort + 3 * cap + begin);
+			k.rays = (const float4 *)(d_rays + begin);
+			k.keys = keys.Current();
+			k.index = index.Current();
+			k.n = count;
+			k.first = 0;
+			// (keys and indices at [0, count) of the chunk's arrays, the indices counted from the batch's first ray)
+			k.index_base = begin;
+			hipLaunchKernelGGL(ray_keys_kernel, dim3((count + 255) / 256), dim3(256), 0, p.aux, k);
+			size_t temp_size = sc.sort_temp_bytes;
+			HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(sc.sort_temp, temp_size, keys, index, (int)count, 0, KEY_BITS, p.aux));
+			uint32_t *bounds = h->d_stream_ctl + CTL_BOUNDS + c * 16;
+			hipLaunchKernelGGL(segment_bounds_kernel, dim3(1), dim3(512), 0, p.aux, keys.Current(), count, bounds);
+			a.chunk_order[c] = index.Current() - begin;  // (indexed by the position in the whole batch)
+			a.chunk_bounds[c] = bounds;
+		}
+		hipLaunchKernelGGL(chunk_ready_kernel, dim3(1), dim3(64), 0, p.aux, h->d_stream_ctl + CTL_READY, c + 1);
+		HIP_TRY(h, hipGetLastError());
+		if (clocked) (void)hipEventRecord(p.clock_ready[c], p.aux), (void)hipEventRecord(p.clock_up[c], p.up);
+		if (c == 0) HIP_TRY(h, hipEventRecord(p.first_ready, p.aux));
+	}
+	HIP_TRY(h, hipEventRecord(p.aux_done, p.aux));
+	// the launch: begun once the first chunk is ready, with less than a CU's LDS so that the sorts find room beside it
+	a.nodes = h->d_nodes;
+	a.tris = h->d_tris;
+	a.rays = (const float4 *)d_rays;
+	a.hits = ANY ? nullptr : (float4 *)d_out_host;
+	a.occluded = ANY ? (uint8_t *)h->d_stage_out : nullptr;
+	a.spill = sc.spill;
+	a.ray_counter = h->d_stream_ctl;
+	a.n_rays = n;
+	a.n_segments = 8;
+	a.node_bytes = h->node_bytes;
+	a.tri_bytes = h->tri_bytes;
+	a.root_ref = h->root_ref;
+	a.refill_min = h->refill_min;
+	a.leaf_min = h->leaf_min;
+	a.drain_leaf_min = h->drain_leaf_min;
+	a.implicit_limit = (int32_t)h->implicit_limit;
+	a.stack_levels = (int32_t)h->stack_levels;
+	a.n_chunks = n_chunks;
+	a.chunks_ready = h->d_stream_ctl + CTL_READY;
+	a.gave_up = h->d_stream_ctl + CTL_GAVE_UP;
+	a.wait_ticks = h->stream_wait_ticks;
+	uint32_t top = h->top_nodes;
+	while (top > 0 && lds_bytes_for(h->stack_levels, top, h->implicit_limit) > h->stream_lds_bytes) top -= std::min<uint32_t>(top, 16);
+	a.top_nodes = (int32_t)top;
+	const uint32_t lds = (uint32_t)lds_bytes_for(h->stack_levels, top, h->implicit_limit);
+	uint32_t blocks = h->grid_blocks;
+	const bool deep = h->spill_levels > 0;
+	if (deep) {
+		const size_t most = sc.spill_words / ((size_t)h->spill_levels * BLOCK);
+		if (most == 0) return fail(h, RTGI_ERR_INVALID, "tree too deep for the spill area");
+		if (blocks > most) blocks = (uint32_t)most;
+	}
+	a.spill_stride = blocks * BLOCK;
+	HIP_TRY(h, hipStreamWaitEvent(p.run, p.first_ready, 0));
+	HIP_TRY(h, (launch_variant<ANY ? 1 : 0>(h->device, false, deep, blocks, lds, p.run, a)));
+	if (clocked) (void)hipEventRecord(p.clock_end, p.run);
+	HIP_TRY(h, hipStreamWaitEvent(p.run, p.aux_done, 0));  // (the scratch is free again when both streams are through)
+	uint32_t gave_up = 0;
+	if (ANY) HIP_TRY(h, hipMemcpyAsync(out, h->d_stage_out, n, hipMemcpyDeviceToHost, p.run));
+	HIP_TRY(h, hipMemcpyAsync(&gave_up, h->d_stream_ctl + CTL_GAVE_UP, sizeof(gave_up), hipMemcpyDeviceToHost, p.run));
+	if (int rc = turn.end()) return rc;
+	HIP_TRY(h, hipStreamSynchronize(p.run));
+	*fell_back = gave_up != 0;
+	++h->streamed_calls;
+	h->streamed_gave_up += gave_up != 0;
+	if (clocked) {
+		fprintf(stderr, "streamed:");
+		for (uint32_t c = 0; c < n_chunks; ++c) {
+			float up = 0, ready = 0;
+			(void)hipEventElapsedTime(&up, p.clock_begin, p.clock_up[c]), (void)hipEventElapsedTime(&ready, p.clock_begin, p.clock_ready[c]);
+			fprintf(stderr, " chunk %u (to ray %u) up %.3f ready %.3f |", c, ends[c], up, ready);
+		}
+		float done = 0;
+		(void)hipEventElapsedTime(&done, p.clock_begin, p.clock_end);
+		fprintf(stderr, " kernel done %.3f ms%s\n", done, gave_up ? " GAVE UP" : "");
+	}
+	if (gave_up && getenv("RTGI_HIP_DEBUG_SYNC")) fprintf(stderr, "[rtgi_hip] streamed host batch: the launch waited in vain for a chunk, tracing the batch in separate launches\n");
+	return RTGI_OK;
+}
+
 template <bool ANY>
 int trace_host(rtgi_hip_tracer *h, const rtgi_ray *rays, uint32_t n, void *out) {
 	if (!h) return RTGI_ERR_INVALID;
@@ -811,6 +1013,18 @@ int trace_host(rtgi_hip_tracer *h, const rtgi_ray *rays, uint32_t n, void *out) 
 	if (rc) return rc;
 	HostPipe &p = *h->pipe;
 	const bool rays_locked = is_page_locked(rays), out_locked = is_page_locked(out);
+	if (h->host_streamed && rays_locked && out_locked && n >= h->stream_min && n < (1u << 31)) {
+		const bool sort = (h->reorder == 1 || (h->reorder == 2 && h->probe_pops > h->reorder_min_pops)) && n >= 4 * h->reorder_min;
+		HIP_TRY(h, hipStreamSynchronize(nullptr));  // (work that earlier calls left on the default stream comes first)
+		bool fell_back = true;
+		rc = trace_host_streamed<ANY>(h, rays, n, out, sort, &fell_back);
+		if (rc != RTGI_OK) {  // nothing of this call stays in flight
+			(void)hipStreamSynchronize(h->pipe->up), (void)hipStreamSynchronize(h->pipe->aux), (void)hipStreamSynchronize(h->pipe->run);
+			return rc;
+		}
+		if (!fell_back) return RTGI_OK;
+		(void)hipStreamSynchronize(h->pipe->up), (void)hipStreamSynchronize(h->pipe->aux);
+	}
 	// Chunks: every chunk's launch ends in a tail of its own, so there are few. From page-locked memory a short first
 	// one (a good quarter of the batch, at most host_lead rays) gets the GPU going early and the rest follows in
 	// parts of up to 5/3 host_chunk rays, each travelling up while its predecessor is traced; from ordinary memory,
@@ -1012,6 +1226,7 @@ void rtgi_hip_destroy(rtgi_hip_tracer *h) {
 	if (h->d_stage_rays) (void)hipFree(h->d_stage_rays);
 	if (h->d_stage_out) (void)hipFree(h->d_stage_out);
 	if (h->d_block_counts) (void)hipFree(h->d_block_counts);
+	if (h->d_stream_ctl) (void)hipFree(h->d_stream_ctl);
 	if (h->scratch_free) (void)hipEventDestroy(h->scratch_free);
 	if (h->pinned) (void)hipHostFree(h->pinned);
 	if (HostPipe *p = h->pipe) {
@@ -1022,6 +1237,16 @@ void rtgi_hip_destroy(rtgi_hip_tracer *h) {
 			if (p->traced[i]) (void)hipEventDestroy(p->traced[i]);
 			if (p->went_down[i]) (void)hipEventDestroy(p->went_down[i]);
 		}
+		for (int i = 0; i < rtgi_dev::MAX_CHUNKS; ++i)
+			if (p->chunk_up[i]) (void)hipEventDestroy(p->chunk_up[i]);
+		if (p->begun) (void)hipEventDestroy(p->begun);
+		for (hipEvent_t e : {p->first_ready, p->aux_done, p->clock_begin, p->clock_end})
+			if (e) (void)hipEventDestroy(e);
+		for (int i = 0; i < rtgi_dev::MAX_CHUNKS; ++i) {
+			if (p->clock_up[i]) (void)hipEventDestroy(p->clock_up[i]);
+			if (p->clock_ready[i]) (void)hipEventDestroy(p->clock_ready[i]);
+		}
+		if (p->aux) (void)hipStreamDestroy(p->aux);
 		if (p->up) (void)hipStreamDestroy(p->up);
 		if (p->run) (void)hipStreamDestroy(p->run);
 		if (p->down) (void)hipStreamDestroy(p->down);
@@ -1822,6 +2047,13 @@ int rtgi_hip_profile_work(rtgi_hip_tracer *h, uint64_t out[4]) {
 	unsigned long long v[4];
 	HIP_TRY(h, hipMemcpy(v, h->d_totals, sizeof(v), hipMemcpyDeviceToHost));
 	for (int k = 0; k < 4; ++k) out[k] = v[k];
+	return RTGI_OK;
+}
+
+int rtgi_hip_host_path_stats(const rtgi_hip_tracer *h, uint64_t *one_launch, uint64_t *gave_up) {
+	if (!h) return RTGI_ERR_INVALID;
+	if (one_launch) *one_launch = h->streamed_calls;
+	if (gave_up) *gave_up = h->streamed_gave_up;
 	return RTGI_OK;
 }
 

@@ -51,6 +51,7 @@ constexpr int MAX_STACK_LDS = 24;  // at most this many pending nodes per lane i
 constexpr int DEEP_STACK_LDS = 20; // trees deeper than MAX_STACK_LDS: this many in LDS, the rest in the global spill area
 constexpr int COUNTER_STRIDE = 32;
 constexpr int MAX_BATCHES = 8;
+constexpr int MAX_CHUNKS = 6;
 constexpr int32_t IDLE = INT32_MIN;  // lane has no ray; leaf references are ~slot with slot < 2^30
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -84,6 +85,17 @@ struct TraceArgs {
 	const float4 *batch_rays[MAX_BATCHES];
 	void *batch_out[MAX_BATCHES];       // float4 per ray (closest_hit) or one byte per ray (any_hit)
 	uint32_t batch_any;                 // bit b: batch b is an any_hit batch
+	// Rays that are still on their way when the launch begins (host batches: the upload of the later parts runs beside
+	// the traversal of the earlier ones). n_chunks > 1: rays [chunk_end[c - 1], chunk_end[c]) form chunk c, with a
+	// permutation and octant bounds of its own (or none); chunk c may be touched once *chunks_ready > c. A wave that has
+	// waited wait_ticks (100 MHz) for a chunk sets *gave_up and ends; the caller then traces what is missing another way.
+	uint32_t n_chunks;
+	uint32_t chunk_end[MAX_CHUNKS];
+	const uint32_t *chunk_order[MAX_CHUNKS];   // indexed by position in the whole batch, like `order`
+	const uint32_t *chunk_bounds[MAX_CHUNKS];  // n_segments + 1 positions relative to the chunk's first
+	const uint32_t *chunks_ready;
+	uint32_t *gave_up;
+	uint32_t wait_ticks;
 	int32_t top_nodes;      // visits to inner nodes 0 .. top_nodes-1 are served from a copy in LDS
 	int32_t stack_levels;   // pending-node slots per lane in LDS; dynamic LDS: see lds_bytes_for()
 	int32_t implicit_limit; // inner nodes below this index are numbered like a heap: children 2i and 2i + 1, no link fetch
@@ -181,8 +193,11 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void trace_kernel(TraceArgs 
 	// Each XCD has its own L2. Waves of one XCD draw rays from the same contiguous part of the batch, so that
 	// an L2 sees neighbouring rays (callers hand rays over in image or sorted order); a wave whose segment is
 	// used up helps with the next one. Placement affects speed only.
-	uint32_t seg = (__builtin_amdgcn_s_getreg(6164) & 15u) % a.n_segments;  // HW_REG_XCC_ID, bits 3:0
+	const uint32_t home_seg = (__builtin_amdgcn_s_getreg(6164) & 15u) % a.n_segments;  // HW_REG_XCC_ID, bits 3:0
+	uint32_t seg = home_seg;
 	uint32_t segs_done = 0;
+	uint32_t chunk = 0;              // wave-uniform: the chunk this wave draws from (0 if the batch is all there)
+	unsigned long long wait_since = 0;  // wave-uniform: when this wave first found the next chunk missing (0: not waiting)
 
 	auto push = [&](int32_t v) {
 		if (!DEEP || sp < stack_levels)
@@ -240,30 +255,67 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void trace_kernel(TraceArgs 
 			const uint32_t want = (uint32_t)__popcll(idle);
 			const int leader = (int)__ffsll((long long)idle) - 1;
 			uint32_t first = 0, avail = 0;
+			const bool chunked = a.n_chunks > 1;
+			const uint32_t *order = a.order;
 			for (;;) {  // draw from this wave's segment; when it is used up, move on to the next one
-				const uint32_t seg_lo = a.seg_bounds ? a.seg_bounds[seg] : (uint32_t)((uint64_t)n_rays * seg / a.n_segments);
-				const uint32_t seg_hi = a.seg_bounds ? a.seg_bounds[seg + 1] : (uint32_t)((uint64_t)n_rays * (seg + 1) / a.n_segments);
+				uint32_t part_lo = 0, part_len = n_rays;  // the chunk's range of positions
+				const uint32_t *bounds = a.seg_bounds;
+				if (chunked) {
+					if (wait_since) {  // the next chunk was not there last time: is it now?
+						// (asked without acquire semantics: an acquire empties this XCD's L2 of what the other waves, and
+						// the sort that everybody is waiting for, are working with; the fence follows once, when the answer is yes)
+						if (__hip_atomic_load(a.chunks_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > chunk) {
+							__atomic_thread_fence(__ATOMIC_ACQUIRE);
+							wait_since = 0;
+						} else {
+							if (__builtin_amdgcn_s_memrealtime() - wait_since > a.wait_ticks) {
+								if (lane == 0) __hip_atomic_store(a.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+								more = false;
+							}
+							break;
+						}
+					}
+					part_lo = chunk ? a.chunk_end[chunk - 1] : 0u;
+					part_len = a.chunk_end[chunk] - part_lo;
+					bounds = a.chunk_bounds[chunk];
+					order = a.chunk_order[chunk];
+				}
+				// (bounds of a chunk were written while this kernel ran: they are read past the caches the kernel keeps)
+				const uint32_t seg_lo = !bounds ? (uint32_t)((uint64_t)part_len * seg / a.n_segments)
+				                        : chunked ? __hip_atomic_load(bounds + seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : bounds[seg];
+				const uint32_t seg_hi = !bounds ? (uint32_t)((uint64_t)part_len * (seg + 1) / a.n_segments)
+				                        : chunked ? __hip_atomic_load(bounds + seg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : bounds[seg + 1];
 				const uint32_t seg_len = seg_hi - seg_lo;
 				uint32_t base = 0;
-				if (lane == leader) base = atomicAdd(a.ray_counter + seg * COUNTER_STRIDE, want);
+				if (lane == leader) base = atomicAdd(a.ray_counter + (chunk * a.n_segments + seg) * COUNTER_STRIDE, want);
 				base = __shfl(base, leader);
 				if (base < seg_len) {
-					first = seg_lo + base;
+					first = part_lo + seg_lo + base;
 					avail = min(want, seg_len - base);
 					break;
 				}
-				if (++segs_done == a.n_segments) {
-					more = false;
-#ifdef RTGI_DIAG
-					dg_t_dry = __builtin_amdgcn_s_memrealtime();
-#endif
+				seg = seg + 1 == a.n_segments ? 0 : seg + 1;
+				if (++segs_done < a.n_segments) continue;
+				if (chunked && chunk + 1 < a.n_chunks) {  // on to the next chunk, once it is there
+					++chunk;
+					segs_done = 0;
+					seg = home_seg;
+					if (__hip_atomic_load(a.chunks_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > chunk) {
+						__atomic_thread_fence(__ATOMIC_ACQUIRE);
+						continue;
+					}
+					wait_since = __builtin_amdgcn_s_memrealtime() | 1ull;
 					break;
 				}
-				seg = seg + 1 == a.n_segments ? 0 : seg + 1;
+				more = false;
+#ifdef RTGI_DIAG
+				dg_t_dry = __builtin_amdgcn_s_memrealtime();
+#endif
+				break;
 			}
 			const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
 			// (an index from the order array is trusted only as far as the batch goes)
-			const uint32_t mine = (rank < avail) ? (a.order ? a.order[first + rank] : first + rank) : 0xffffffffu;
+			const uint32_t mine = (rank < avail) ? (order ? order[first + rank] : first + rank) : 0xffffffffu;
 			if (cur == IDLE && mine < n_rays) {
 				uint32_t local = mine;
 				if (MIXED) {  // which batch, and which ray of it
@@ -295,6 +347,8 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void trace_kernel(TraceArgs 
 		const unsigned long long busy = __ballot(cur != IDLE);
 		if (busy == 0) {
 			if (!more) break;
+			if (wait_since)  // nothing to do until the next chunk arrives: a few microseconds out of everybody's way
+				for (int nap = 0; nap < 8; ++nap) __builtin_amdgcn_s_sleep(127);
 			continue;
 		}
 		const bool wave_plain = __ballot(cur != IDLE && !plain) == 0;
@@ -490,6 +544,7 @@ struct KeyArgs {
 	float inv_diagonal;
 	uint32_t n;
 	uint32_t first;  // position of this batch's first ray in the launch: keys and indices go to [first, first + n)
+	uint32_t index_base;  // added to the indices written (a chunk of a batch, sorted on its own: its first ray's number)
 };
 __device__ __forceinline__ uint32_t spread3(uint32_t v) {  // 6 bits -> every third bit
 	v = (v | (v << 8)) & 0x0000F00Fu;
@@ -528,7 +583,13 @@ __global__ __launch_bounds__(256) void ray_keys_kernel(KeyArgs a) {
 	const float rel = ray_span(a, q0, q1) * a.inv_diagonal * (top + 1.0f);
 	const uint32_t cls = (uint32_t)top - (uint32_t)__builtin_fminf(__builtin_fmaxf(rel == rel ? rel : 0.0f, 0.0f), top);
 	a.keys[a.first + i] = (octant << 21) | (cls << (21 - CLASS_BITS)) | (morton >> (CLASS_BITS - 3));
-	a.index[a.first + i] = a.first + i;
+	a.index[a.first + i] = a.index_base + a.first + i;
+}
+
+// Announces that a chunk of a batch (its rays and its permutation) is in place: runs on the stream that put it there,
+// after that work; the traversal kernel, already running, reads the word with acquire semantics.
+__global__ void chunk_ready_kernel(uint32_t *chunks_ready, uint32_t value) {
+	if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(chunks_ready, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Positions in the sorted key array where the direction octant changes: the 8 parts of the batch that the 8

@@ -501,3 +501,84 @@ def test_handle_on_another_gpu_than_the_current_one():
     assert_hits_equal(t.closest_hit(rays), o.closest_hit(rays), "host batch on GPU 1")
     assert np.array_equal(t.any_hit(rays), o.any_hit(rays))
     assert torch.cuda.current_device() == 0
+
+
+def _page_locked_copy(a):
+    """(pointer, numpy view) of a page-locked copy of a C-contiguous array."""
+    import ctypes
+    L = tracer.lib()
+    ptr = L.rtgi_hip_host_alloc(max(a.nbytes, 16))
+    assert ptr
+    view = np.frombuffer((ctypes.c_char * a.nbytes).from_address(ptr), dtype=a.dtype).reshape(a.shape)
+    view[...] = a
+    return ptr, view
+
+
+@pytest.mark.parametrize("scene,cmds,reorder", [("soup", (), "on"), ("soup", (), "off"), ("skewed", ("sm",), "auto")])
+def test_page_locked_host_batches_in_one_launch(scene, cmds, reorder):
+    """Host batches in page-locked memory go through the GPU in one launch that takes up the later chunks of the batch
+    while it runs (each chunk sorted on its own): results are those of the device entry points, ray by ray."""
+    import torch
+    pos, tri, _ = scenes.soup(60000, seed=2, size=0.2) if scene == "soup" else scenes.skewed(60000, seed=6)
+    t = tracer.HipBvhTracer(layout="indexed")
+    _configure(t, cmds)
+    t.build(pos, tri)
+    assert t.interprete("hip", "reorder " + reorder)
+    n = 700001
+    rays = _mixed_rays(pos, n, seed=33)
+    d_rays = torch.from_numpy(rays).cuda()
+    d_hits = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+    d_occ = torch.empty(n, dtype=torch.uint8, device="cuda")
+    t.closest_hit_device(d_rays, d_hits)
+    t.any_hit_device(d_rays, d_occ)
+    torch.cuda.synchronize()
+    want, want_any = d_hits.cpu().numpy().view(tracer.HIT_DTYPE).reshape(-1), d_occ.cpu().numpy()
+    L = tracer.lib()
+    p_rays, v_rays = _page_locked_copy(rays)
+    p_hits, v_hits = _page_locked_copy(np.zeros(n, tracer.HIT_DTYPE))
+    p_occ, v_occ = _page_locked_copy(np.full(n, 7, np.uint8))
+    try:
+        for _ in range(2):  # (twice: the second call finds the streams, events and buffers of the first)
+            v_hits.view(np.uint8)[...] = 0xAB
+            t._check(L.rtgi_hip_closest_hit(t._h, p_rays, n, p_hits))
+            assert_hits_equal(v_hits, want, "page-locked closest_hit")
+            t._check(L.rtgi_hip_any_hit(t._h, p_rays, n, p_occ))
+            assert (v_occ == want_any).all()
+        assert t.host_path_stats() == dict(one_launch=4, gave_up=0)
+        o = _oracle_for(pos, tri, "indexed", False, cmds)
+        sample = np.arange(0, n, 8)
+        assert_hits_equal(v_hits[sample], o.closest_hit(rays[sample]), "page-locked closest_hit against the oracle")
+    finally:
+        for ptr in (p_rays, p_hits, p_occ):
+            L.rtgi_hip_host_free(ptr)
+    t.close()
+
+
+def test_page_locked_host_batch_whose_launch_gives_up(monkeypatch):
+    """A one-launch host batch whose launch does not see the later parts of the batch arrive in time (here: it waits for
+    10 nanoseconds) ends without them, says so, and the batch is traced chunk by chunk: same results, no hang."""
+    import torch
+    monkeypatch.setenv("RTGI_HIP_STREAM_WAIT_TICKS", "1")
+    monkeypatch.setenv("RTGI_HIP_STREAM_PARTS", "0.02,0.5,1")  # (a first part that is used up long before the second is there)
+    pos, tri, _ = scenes.soup(60000, seed=2, size=0.2)
+    t = tracer.HipBvhTracer(layout="indexed")
+    t.build(pos, tri)
+    assert t.interprete("hip", "reorder on")
+    n = 900000
+    rays = _mixed_rays(pos, n, seed=34)
+    d_rays = torch.from_numpy(rays).cuda()
+    d_hits = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+    t.closest_hit_device(d_rays, d_hits)
+    torch.cuda.synchronize()
+    want = d_hits.cpu().numpy().view(tracer.HIT_DTYPE).reshape(-1)
+    L = tracer.lib()
+    p_rays, _ = _page_locked_copy(rays)
+    p_hits, v_hits = _page_locked_copy(np.zeros(n, tracer.HIT_DTYPE))
+    try:
+        v_hits.view(np.uint8)[...] = 0xAB
+        t._check(L.rtgi_hip_closest_hit(t._h, p_rays, n, p_hits))
+        assert_hits_equal(v_hits, want, "page-locked closest_hit after the launch gave up")
+        assert t.host_path_stats() == dict(one_launch=1, gave_up=1)
+    finally:
+        L.rtgi_hip_host_free(p_rays), L.rtgi_hip_host_free(p_hits)
+    t.close()
