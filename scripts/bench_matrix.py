@@ -35,7 +35,13 @@ CASES = {
                    ((0, 0, 0), (0, 0, -1), (0, 1, 0)), (1920, 1080), (3.0, 8.0, 5.0)),
     "skewed4m_sm": ("skewed", dict(n_tris=1 << 22, seed=5), "indexed", "sm", ((0, 0.5, 12), (0, 0, -1), (0, 1, 0)),
                     (1920, 1080), (2.0, 9.0, 4.0)),
+    # 40 sheets of doubling size under spatial-median splits: a chain of 40 levels, deeper than the part of the stack
+    # that lives in LDS; the "grazing" population runs along the chain and keeps a node pending per sheet ahead
+    "stadium4m_sm": ("stadium_sheets", dict(n_tris=1 << 22, sheets=40), "indexed", "sm", ((2.0, 0.0, 0.0), (-1, 0, 0), (0, 1, 0)),
+                     (1920, 1080), (1.0, 0.3, 0.2)),
 }
+# further populations of a case: name -> (generator in scenes, kwargs)
+EXTRA_RAYS = {"stadium4m_sm": {"grazing": ("stadium_rays", dict(n=1 << 20, seed=3, sheets=40))}}
 
 
 def time_calls(fn, sync, seconds=0.25, min_calls=3):
@@ -96,11 +102,16 @@ def main():
             t0 = time.time()
             oracle = orc.Bbvh(pos, tri, layout=layout, **_oracle_split(bvh))
             print("[%s] oracle build %.1f s" % (name, time.time() - t0), flush=True)
-        for pop, d_rays, any_hit in (("primary", d_primary, False), ("shadow", d_shadow, True), ("bounce", d_bounce, False)):
+        populations = [("primary", d_primary, False), ("shadow", d_shadow, True), ("bounce", d_bounce, False)]
+        for pop, (gen_rays, kw_rays) in EXTRA_RAYS.get(name, {}).items():
+            populations.append((pop, torch.from_numpy(getattr(scenes, gen_rays)(**kw_rays)).to(dev), False))
+        stack = t.profile_details()
+        for pop, d_rays, any_hit in populations:
             n = d_rays.shape[0]
             if n == 0:
                 continue
             d_cnt = torch.zeros((n, 2), dtype=torch.int32, device=dev)
+            t.profile_begin()
             if any_hit:
                 d_out = torch.empty((n,), dtype=torch.uint8, device=dev)
                 call = lambda: t.any_hit_device(d_rays, d_out)
@@ -110,6 +121,8 @@ def main():
                 call = lambda: t.closest_hit_device(d_rays, d_out)
                 t.closest_hit_device(d_rays, d_out, d_cnt)
             sync()
+            spill_pushes = t.profile_details()["spill_pushes"]
+            t.profile_end()
             s = d_cnt.sum(0, dtype=torch.int64).cpu().numpy()
             per_tri = 52 + (4 if layout == "indexed" else 0)
             total = (32 + (1 if any_hit else 16)) * n + 56 * int(s[0]) + per_tri * int(s[1])
@@ -129,6 +142,8 @@ def main():
                    "kernel_ms": round(kernel_ms, 4), "inner_pops_per_ray": round(float(s[0]) / n, 2),
                    "triangle_tests_per_ray": round(float(s[1]) / n, 3), "hit_or_occluded_fraction": round(positive, 4),
                    "algorithmic_bytes_per_ray": round(total / n, 1),
+                   "stack_levels_lds": stack["lds_levels"], "stack_levels_spill": stack["spill_levels"],
+                   "spill_pushes_per_ray": round(spill_pushes / n, 3),
                    "roofline_frac_of_8TBs": round(total / (kernel_ms * 1e-3) / 8e12, 4)}
             if oracle is not None:
                 rays = d_rays.cpu().numpy()
