@@ -129,7 +129,7 @@ def algorithmic_bytes(t, d_rays, layout):
     t.profile_end()
     return dict(bytes=total, pops=float(s[0]) / n, tests=float(s[1]) / n, hit_rate=hit_rate, lane_loads=int(lane_loads),
                 lds_share=work[3] / max(work[1], 1), max_pops=int(d_cnt[:, 0].max().item()), hits=d_hits,
-                link_fetch_share=details["link_fetches"] / max(work[1], 1))
+                link_fetch_share=details["link_fetches"] / max(work[1], 1), link_fetches=int(details["link_fetches"]))
 
 
 def cpu_baseline(args, w, gpu_hits):
@@ -238,18 +238,20 @@ def host_buffer_rates(t, rays, d_hits):
 
 
 def gather_ceiling():
-    """(16-byte lane loads per second, 64-byte L2-miss records per second, source) of this GPU, measured now by
-    scripts/ubench/gather_mix if it has been built, else the figures recorded under profiles/."""
+    """(16-byte lane loads per second with four loads per 64-byte record, 64-byte L2-miss records per second, source,
+    lane loads per second with three loads per record or None) of this GPU, measured now by scripts/ubench/gather_mix
+    if it has been built, else the figures recorded under profiles/."""
     import subprocess
     exe = os.path.join(ROOT, "scripts", "ubench", "gather_mix")
     if os.path.exists(exe):
         try:
             out = subprocess.run([exe, "4", "quick"], capture_output=True, text=True, timeout=60).stdout
             vals = dict(line.split() for line in out.splitlines() if line.startswith(("LANE_LOADS", "MISS_RECORDS")))
-            return float(vals["LANE_LOADS_PER_S"]), float(vals["MISS_RECORDS_PER_S"]), "measured on this GPU by scripts/ubench/gather_mix"
+            three = float(vals["LANE_LOADS_PER_S_3"]) if "LANE_LOADS_PER_S_3" in vals else None
+            return float(vals["LANE_LOADS_PER_S"]), float(vals["MISS_RECORDS_PER_S"]), "measured on this GPU by scripts/ubench/gather_mix", three
         except (OSError, KeyError, ValueError, subprocess.SubprocessError):
             pass
-    return LANE_LOADS_PER_S_FALLBACK, MISS_RECORDS_PER_S_FALLBACK, "profiles/r02_ubench_gather_mix_3waves.txt"
+    return LANE_LOADS_PER_S_FALLBACK, MISS_RECORDS_PER_S_FALLBACK, "profiles/r02_ubench_gather_mix_3waves.txt", None
 
 
 def kernel_source_hash():
@@ -353,7 +355,7 @@ def main():
 
     alg = algorithmic_bytes(t, d_rays, args.layout)
     total_bytes, pops, tests, hit_rate = alg["bytes"], alg["pops"], alg["tests"], alg["hit_rate"]
-    lane_rate, miss_rate, rate_source = gather_ceiling() if rank == 0 else (LANE_LOADS_PER_S_FALLBACK, MISS_RECORDS_PER_S_FALLBACK, "")
+    lane_rate, miss_rate, rate_source, lane_rate3 = gather_ceiling() if rank == 0 else (LANE_LOADS_PER_S_FALLBACK, MISS_RECORDS_PER_S_FALLBACK, "", None)
 
     def barrier():
         torch.cuda.synchronize(device)
@@ -405,7 +407,7 @@ def main():
                 "primary_hit_rate": round(w["primary_hit_rate"], 4),
                 "bvh_build_s": round(w["build_s"], 2),
             },
-            "roofline": roofline(args.workload, total_bytes, n, kernel_ms, alg, lane_rate, miss_rate, rate_source),
+            "roofline": roofline(args.workload, total_bytes, n, kernel_ms, alg, lane_rate, miss_rate, rate_source, lane_rate3),
         }
         if world == 1 and not args.no_extra:
             out["extra"] = other_ray_kinds(args, w, device)
@@ -492,7 +494,7 @@ def frame_mode(args, world, rank, device, grouped):
     r.close()
 
 
-def roofline(workload, total_bytes, n, kernel_ms, alg, lane_rate, miss_rate, rate_source):
+def roofline(workload, total_bytes, n, kernel_ms, alg, lane_rate, miss_rate, rate_source, lane_rate3=None):
     """What the dominant kernel runs against, and how close it is.
 
     `achieved` is the reference's algorithmic bytes per launch over the kernel time, measured here with HIP events on the
@@ -504,14 +506,17 @@ def roofline(workload, total_bytes, n, kernel_ms, alg, lane_rate, miss_rate, rat
                         vector cache, TD: data return) and of the SIMDs, as the hardware counters report them
       frac              the largest of the times each resource needs for this launch's work alone / kernel time, with
                         `bound` naming that resource and `peak` = the algorithmic bytes over that time. Resources:
-        lane loads   16-byte loads of lanes going to different lines (counted by the kernel itself) / measured rate
+        lane loads   16-byte loads of lanes going to different lines (counted by the kernel itself) / measured rate; the
+                     rate is measured with four loads per 64-byte record (visits that fetch their links) and with three
+                     (all other visits, triangles), and each kind of load is priced at its own
         valu         vector instructions x 4 cycles on 1024 SIMDs
         beyond L2    L2 misses / measured rate of random 64-byte fetches that miss L2
         hbm          bytes beyond L2 / 8 TB/s
         chain        the longest ray's inner-node visits x the latency of one dependent fetch
     The counters under profiles/ are used only if they were taken with this kernel source (hash) and workload."""
     t_kernel = kernel_ms * 1e-3
-    times = {"lane_loads": alg["lane_loads"] / lane_rate, "chain": alg["max_pops"] * 355e-9}
+    loads4 = min(4 * alg["link_fetches"], alg["lane_loads"]) if lane_rate3 else alg["lane_loads"]
+    times = {"lane_loads": loads4 / lane_rate + (alg["lane_loads"] - loads4) / (lane_rate3 or lane_rate), "chain": alg["max_pops"] * 355e-9}
     pmc = _measured_counters(workload)
     if pmc:
         times["valu"] = pmc["valu_instructions"] * VALU_CYCLES_PER_INSTRUCTION / SIMDS / (pmc["clock_ghz"] * 1e9)
@@ -541,6 +546,7 @@ def roofline(workload, total_bytes, n, kernel_ms, alg, lane_rate, miss_rate, rat
         "floor_ms_by_resource": {k: round(v * 1e3, 4) for k, v in sorted(times.items())},
         "lane_loads_per_launch": alg["lane_loads"],
         "lane_load_rate_per_s": lane_rate,
+        "lane_load_rate_three_per_record_per_s": lane_rate3,
         "lane_load_rate_source": rate_source,
         "inner_visits_served_from_lds": round(alg["lds_share"], 4),
         "inner_visits_that_fetch_links": round(alg["link_fetch_share"], 4),

@@ -3,7 +3,9 @@
 prices its ceilings with: per-launch counters of the traversal kernel on the workload's bounce batch, tagged with
 the hash of the kernel source they were taken with.
 
-    scripts/pmc_to_traffic.py gpurun_out/pmc_<tag> <workload>
+    scripts/pmc_to_traffic.py gpurun_out/pmc_<tag> <workload> [summary.txt]
+
+summary.txt, if named, receives every counter's mean per averaged launch as text (the files profiles/*_pmc_summary.txt).
 
 The closest_hit launches of a bench run are: one over the camera rays (first), one counting launch, then the
 bounce-batch launches that are averaged here. bytes beyond L2 = (FETCH_SIZE x 1.20 + WRITE_SIZE) x 1024: the
@@ -44,6 +46,15 @@ def main():
     pmc_dir, workload = sys.argv[1], sys.argv[2]
     c = per_launch(pmc_dir)
     ns = [v for k, v in c.items() if k.startswith("_ns:")]
+    if len(sys.argv) > 3:
+        with open(sys.argv[3], "w") as f:
+            f.write("rtgi_dev::trace_kernel<0, false, false>, mean per launch over the bounce-batch launches of each pass\n")
+            for k in sorted(c):
+                if k.startswith("_ns:"):
+                    f.write(" %-44s %.6g\n" % ("launch duration in pass %s [ns]" % k[4:], c[k]))
+            for k in sorted(c):
+                if not k.startswith("_ns:"):
+                    f.write(" %-44s %.6g\n" % (k, c[k]))
     cus, simds, xcds = 256, 1024, 8
 
     def per(name, unit_count, elapsed_pass):

@@ -6,6 +6,7 @@
 // Usage: gather_mix [waves_per_simd=3] [quick]
 // quick: only the 64-byte / 4-load form at hit shares 0.77 and 0, one line each for bench.py to read:
 //   LANE_LOADS_PER_S <16-byte lane loads per second at 77 % L2 hits>   MISS_RECORDS_PER_S <64-byte records per second, no L2 hits>
+//   LANE_LOADS_PER_S_3 <the first, with three loads per record instead of four>
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -56,13 +57,15 @@ int main(int argc, char **argv) {
 	const unsigned p_list[] = {0, 256, 512, 788, 922, 1024};  // share of fetches that go to the hot region, in 1/1024
 	const unsigned hot_bytes = 1u << 20;                        // 1 MiB: stays in each XCD's 4 MiB L2
 	if (argc > 2 && std::string(argv[2]) == "quick") {
-		double rate[2];
-		const unsigned p_quick[2] = {788, 0};
-		for (int k = 0; k < 2; ++k) {
+		// [0] 4 loads per record, 77 % hits; [1] 4 loads, no hits; [2] 3 loads per record (the first 48 bytes), 77 % hits
+		double rate[3];
+		const unsigned p_quick[3] = {788, 0, 788};
+		for (int k = 0; k < 3; ++k) {
 			float best = 1e30f;
 			for (int rep = 0; rep < 3; ++rep) {
 				CHECK(hipEventRecord(e0));
-				hipLaunchKernelGGL((gather<4, 6>), dim3(blocks), dim3(256), 0, 0, table, max_bytes, max_bytes >> 6, hot_bytes >> 6, p_quick[k], iters, out);
+				if (k < 2) hipLaunchKernelGGL((gather<4, 6>), dim3(blocks), dim3(256), 0, 0, table, max_bytes, max_bytes >> 6, hot_bytes >> 6, p_quick[k], iters, out);
+				else hipLaunchKernelGGL((gather<3, 6>), dim3(blocks), dim3(256), 0, 0, table, max_bytes, max_bytes >> 6, hot_bytes >> 6, p_quick[k], iters, out);
 				CHECK(hipEventRecord(e1));
 				CHECK(hipEventSynchronize(e1));
 				float ms;
@@ -71,7 +74,7 @@ int main(int argc, char **argv) {
 			}
 			rate[k] = (double)blocks * 256 * iters / (best * 1e-3);
 		}
-		printf("LANE_LOADS_PER_S %.4g\nMISS_RECORDS_PER_S %.4g\n", 4 * rate[0], rate[1]);
+		printf("LANE_LOADS_PER_S %.4g\nMISS_RECORDS_PER_S %.4g\nLANE_LOADS_PER_S_3 %.4g\n", 4 * rate[0], rate[1], 3 * rate[2]);
 		return 0;
 	}
 	printf("waves per SIMD %d; hot region %u KiB, table %u MiB\n", waves_per_simd, hot_bytes >> 10, max_bytes >> 20);
