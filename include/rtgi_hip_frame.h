@@ -113,6 +113,13 @@ int rtgi_hip_renderer_render(rtgi_hip_renderer *r, const rtgi_frame *frame, floa
  * time of the call; either may be NULL. The caller's current GPU is left as it was. */
 int rtgi_hip_renderer_rt_bench(rtgi_hip_renderer *r, const rtgi_frame *frame, uint64_t *n_rays, double *ms);
 
+/* Which share of a frame part `rank` of `world` takes (host code only, no GPU needed; what rtgi_hip_renderer_render deals
+ * by): with RTGI_SHARD_TILES the pixels y * w + x of every world-th tile of `tile` x `tile` pixels (0 = 64) starting with
+ * tile `rank`, tiles numbered row by row, pixels of a tile row by row; with RTGI_SHARD_SAMPLES the sample indices
+ * rank, rank + world, ... below sppx. *n receives their number; out, if not NULL, must have room for them
+ * (call once with NULL to learn *n). */
+int rtgi_hip_frame_share(uint32_t sharding, int w, int h, uint32_t tile, uint32_t sppx, int world, int rank, uint32_t *out, uint32_t *n);
+
 const char *rtgi_hip_renderer_last_error(const rtgi_hip_renderer *r);
 
 #ifdef __cplusplus

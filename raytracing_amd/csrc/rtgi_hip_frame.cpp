@@ -144,6 +144,14 @@ void tile_pixels(int w, int h, uint32_t tile, int world, int rank, std::vector<u
 		}
 }
 
+// The samples of a pixel that part `rank` of `world` takes: first, first + step, ... (all of them unless the frame is
+// shared by samples).
+void sample_share(uint32_t sharding, int world, int rank, uint32_t &first, uint32_t &step) {
+	const bool by_samples = world > 1 && sharding == RTGI_SHARD_SAMPLES;
+	first = by_samples ? (uint32_t)rank : 0u;
+	step = by_samples ? (uint32_t)world : 1u;
+}
+
 // This part's share of the frame, up to its framebuffer in place in p.d_full (zero where it has no samples).
 int render_part(Part &p, const rtgi_frame &f, int rank, int world) {
 	PART_HIP(p, hipSetDevice(p.device));
@@ -167,9 +175,9 @@ int render_part(Part &p, const rtgi_frame &f, int rank, int world) {
 	}
 	float *fb = by_tiles ? p.d_fb : p.d_full;  // framebuffer::clear
 	PART_HIP(p, hipMemsetAsync(fb, 0, (size_t)std::max<uint32_t>(n, 1) * 16, st));
-	const int step = (world > 1 && f.sharding == RTGI_SHARD_SAMPLES) ? world : 1;
-	const int first = step > 1 ? rank : 0;
-	for (uint32_t sample = (uint32_t)first; sample < f.sppx && n > 0; sample += (uint32_t)step) {
+	uint32_t first, step;
+	sample_share(f.sharding, world, rank, first, step);
+	for (uint32_t sample = first; sample < f.sppx && n > 0; sample += step) {
 		const float *offsets = nullptr;
 		if (f.jitter) {
 			if (d_pixels)
@@ -637,6 +645,24 @@ int rtgi_hip_renderer_rt_bench(rtgi_hip_renderer *r, const rtgi_frame *frame, ui
 	if (e != hipSuccess) return fail(r, RTGI_ERR_DEVICE, std::string("rt_bench: ") + hipGetErrorString(e));
 	if (n_rays) *n_rays = n;
 	if (ms) *ms = elapsed;
+	return RTGI_OK;
+}
+
+int rtgi_hip_frame_share(uint32_t sharding, int w, int h, uint32_t tile, uint32_t sppx, int world, int rank, uint32_t *out, uint32_t *n) {
+	if (!n || world < 1 || rank < 0 || rank >= world || sharding > RTGI_SHARD_SAMPLES) return RTGI_ERR_INVALID;
+	if (sharding == RTGI_SHARD_SAMPLES) {
+		uint32_t count = 0, first, step;
+		sample_share(sharding, world, rank, first, step);
+		for (uint32_t sample = first; sample < sppx; sample += step, ++count)
+			if (out) out[count] = sample;
+		*n = count;
+		return RTGI_OK;
+	}
+	if (w < 1 || h < 1) return RTGI_ERR_INVALID;
+	std::vector<uint32_t> pixels;
+	tile_pixels(w, h, tile ? tile : 64u, world, rank, pixels);
+	*n = (uint32_t)pixels.size();
+	if (out) std::copy(pixels.begin(), pixels.end(), out);
 	return RTGI_OK;
 }
 

@@ -22,7 +22,24 @@ SHARDING = {"tiles": 0, "samples": 1}
 EXPORTS = [
     "rtgi_hip_renderer_create", "rtgi_hip_renderer_unique_id", "rtgi_hip_renderer_create_rank", "rtgi_hip_renderer_destroy", "rtgi_hip_renderer_device_count", "rtgi_hip_renderer_handle",
     "rtgi_hip_renderer_interprete", "rtgi_hip_renderer_build", "rtgi_hip_renderer_set_materials", "rtgi_hip_renderer_set_textures", "rtgi_hip_renderer_render", "rtgi_hip_renderer_rt_bench", "rtgi_hip_renderer_last_error",
+    "rtgi_hip_frame_share",
 ]
+
+
+def frame_share(sharding, w, h, tile, sppx, world, rank):
+    """The pixels (sharding "tiles") or sample indices ("samples") that part `rank` of `world` takes of a frame, as the
+    frame library deals them (host code, needs no GPU)."""
+    import numpy as np
+    L = lib()
+    kind = {"tiles": 0, "samples": 1}[sharding]
+    n = C.c_uint32(0)
+    rc = L.rtgi_hip_frame_share(kind, w, h, tile, sppx, world, rank, None, C.byref(n))
+    if rc:
+        raise ValueError("rtgi_hip_frame_share refused its arguments (%d)" % rc)
+    out = np.empty(n.value, np.uint32)
+    if n.value:
+        L.rtgi_hip_frame_share(kind, w, h, tile, sppx, world, rank, out.ctypes.data, C.byref(n))
+    return out
 
 
 class Camera(C.Structure):
@@ -69,6 +86,7 @@ def lib():
         L.rtgi_hip_renderer_render.argtypes = [vp, C.POINTER(Frame), vp, vp, C.POINTER(FrameStats)]
         L.rtgi_hip_renderer_rt_bench.argtypes = [vp, C.POINTER(Frame), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
         L.rtgi_hip_renderer_last_error.argtypes = [vp]
+        L.rtgi_hip_frame_share.argtypes = [u32, i32, i32, u32, u32, i32, i32, vp, C.POINTER(u32)]
         L.rtgi_hip_renderer_last_error.restype = cp
         _lib = L
     return _lib

@@ -96,3 +96,35 @@ def test_bench_reports_slowest_rank_and_all_rays(tmp_path):
         assert np.load(tmp_path / ("job_%d.npy" % rank)).tolist() == [2.0, 300.0]
     import bench
     assert bench.whole_job(0.5, 7, "cpu", False) == (0.5, 7.0)
+
+
+@pytest.mark.parametrize("w,h,tile,world", [(96, 64, 32, 2), (100, 37, 16, 3), (1920, 1080, 64, 8), (64, 64, 64, 4), (5, 3, 0, 2)])
+def test_the_frame_library_deals_tiles_as_the_gloo_tests_assume(w, h, tile, world):
+    """The C++ frame level (what runs on N GPUs) and rd.shard_tiles (what the world-size-2 gloo tests exercise)
+    deal the same pixels to the same rank in the same order, and the ranks' shares partition the frame."""
+    from raytracing_amd import frame
+    seen = np.zeros(w * h, np.int32)
+    for rank in range(world):
+        pixels = frame.frame_share("tiles", w, h, tile, 1, world, rank)
+        want = [y * w + x for (x0, y0, x1, y1) in rd.shard_tiles(w, h, world, rank, tile or 64)
+                for y in range(y0, y1) for x in range(x0, x1)]
+        assert pixels.tolist() == want
+        seen[pixels] += 1
+    assert (seen == 1).all()
+
+
+@pytest.mark.parametrize("sppx,world", [(64, 8), (7, 2), (1, 4), (0, 2)])
+def test_the_frame_library_deals_samples_as_the_gloo_tests_assume(sppx, world):
+    from raytracing_amd import frame
+    dealt = []
+    for rank in range(world):
+        samples = frame.frame_share("samples", 16, 16, 0, sppx, world, rank)
+        assert samples.tolist() == rd.shard_samples(sppx, world, rank)
+        dealt += samples.tolist()
+    assert sorted(dealt) == list(range(sppx))
+
+
+def test_frame_share_refuses_ranks_outside_the_world():
+    from raytracing_amd import frame
+    with pytest.raises(ValueError):
+        frame.frame_share("tiles", 8, 8, 4, 1, 2, 2)
