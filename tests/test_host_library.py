@@ -240,7 +240,7 @@ def test_zero_surface_ranges_terminate(cmds):
 def test_frame_library_exports_every_declared_symbol():
     from raytracing_amd import frame
     header = open(os.path.join(ROOT, "include", "rtgi_hip_frame.h")).read()
-    declared = sorted(set(re.findall(r"\b(rtgi_hip_renderer_[a-z_0-9]+)\s*\(", header)))
+    declared = sorted(set(re.findall(r"\b(rtgi_hip_(?:renderer|frame)_[a-z_0-9]+)\s*\(", header)))
     assert declared == sorted(frame.EXPORTS)
     ctypes.CDLL(tracer.LIB_PATH, mode=ctypes.RTLD_GLOBAL)
     lib = ctypes.CDLL(frame.LIB_PATH)
