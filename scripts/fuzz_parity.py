@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity campaign: random scenes, tree settings and ray mixes, GPU against the CPU oracle, bit for bit
-(hits, any-hit bytes, per-ray counts). Runs until the time budget is used; prints one line per configuration and
+(hits, any-hit bytes, per-ray counts; the counting and the plain instantiation of the kernel, and for large batches the
+host-buffer entry point on page-locked memory). Runs until the time budget is used; prints one line per configuration and
 stops at the first difference.
 
     python scripts/fuzz_parity.py [--seconds 120] [--seed 0]
@@ -30,7 +31,7 @@ def main():
     t_end = time.time() + args.seconds
     done = 0
     while time.time() < t_end:
-        kind = rs.choice(["soup", "cornell", "sponza", "terrain", "skewed"])
+        kind = rs.choice(["soup", "cornell", "sponza", "terrain", "skewed", "stadium"])
         size = int(rs.choice([300, 3000, 30000, 150000]))
         seed = int(rs.randint(0, 1 << 30))
         if kind == "soup":
@@ -41,6 +42,9 @@ def main():
             pos, tri, _ = scenes.sponza_class(max(size, 3000), seed=seed)
         elif kind == "terrain":
             pos, tri, _ = scenes.terrain_objects(max(size, 3000), seed=seed)
+        elif kind == "stadium":  # a chain of sheets: deep trees under sm, stacks beyond the part kept in LDS
+            sheets = int(rs.choice([26, 34, 44]))
+            pos, tri, _ = scenes.stadium_sheets(max(size, 3000), sheets=sheets, seed=seed)
         else:
             pos, tri, _ = scenes.skewed(size, seed=seed)
         layout = str(rs.choice(["flat", "indexed"]))
@@ -48,7 +52,7 @@ def main():
         split = str(rs.choice(["om", "sm", "sah"]))
         planes = int(rs.choice([1, 4, 16, 63]))
         max_tris = int(rs.choice([1, 1, 2, 5, 16]))
-        n = int(rs.choice([1000, 70000, 200000]))
+        n = int(rs.choice([1000, 70000, 200000, 560000]))
         reorder = str(rs.choice(["auto", "on", "off"]))
         t = tracer.HipBvhTracer(layout=layout, esc=esc)
         if split == "sah":
@@ -67,6 +71,8 @@ def main():
         o = orc.Bbvh(pos, tri, layout=layout, esc=esc, split=split, planes=planes if split == "sah" else 0, max_tris=max_tris)
         assert t.nodes().tobytes() == o.nodes().tobytes(), "tree differs: " + label
         rays = _mixed_rays(pos, n, seed=seed % 1000)
+        if kind == "stadium":  # half of the rays along the chain
+            rays[::2] = scenes.stadium_rays((n + 1) // 2, seed=seed % 1000, sheets=sheets)
         d_rays = torch.from_numpy(rays).cuda()
         d_hits = torch.empty((n, 4), dtype=torch.float32, device="cuda")
         d_occ = torch.empty(n, dtype=torch.uint8, device="cuda")
@@ -80,6 +86,25 @@ def main():
         want_any, want_any_counts = o.any_hit(rays, counts=True)
         assert (d_occ.cpu().numpy() == want_any).all(), "any_hit differs: " + label
         assert (d_cnt.cpu().numpy().astype(np.uint32) == want_any_counts[:, 0:2]).all(), "any_hit counts differ: " + label
+        # the instantiation without counters (the one that is timed)
+        d_hits.fill_(-1.0)
+        d_occ.fill_(7)
+        t.closest_hit_device(d_rays, d_hits)
+        t.any_hit_device(d_rays, d_occ)
+        assert_hits_equal(d_hits.cpu().numpy().view(tracer.HIT_DTYPE).reshape(-1), want, "plain kernel: " + label)
+        assert (d_occ.cpu().numpy() == want_any).all(), "plain any_hit differs: " + label
+        if n >= 500000:  # host buffers in page-locked memory: one launch that takes up the batch as it arrives
+            import ctypes
+            L = tracer.lib()
+            p_rays, p_hits = L.rtgi_hip_host_alloc(rays.nbytes), L.rtgi_hip_host_alloc(n * 16)
+            assert p_rays and p_hits
+            ctypes.memmove(p_rays, rays.ctypes.data, rays.nbytes)
+            ctypes.memset(p_hits, 0xAB, n * 16)
+            t._check(L.rtgi_hip_closest_hit(t._h, p_rays, n, p_hits))
+            got = np.frombuffer(ctypes.string_at(p_hits, n * 16), dtype=tracer.HIT_DTYPE)
+            L.rtgi_hip_host_free(p_rays), L.rtgi_hip_host_free(p_hits)
+            assert_hits_equal(got, want, "page-locked host batch: " + label)
+            label += ", host path %s" % t.host_path_stats()
         t.close()
         done += 1
         print("ok  depth %2d  %s" % (o.depth, label), flush=True)
