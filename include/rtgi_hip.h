@@ -144,7 +144,8 @@ int rtgi_hip_any_hit(rtgi_hip_tracer *h, const rtgi_ray *rays, uint32_t n, uint8
 /* How the page-locked batches of the two calls above went (no counterpart in the reference): *one_launch = batches traced
  * by one launch beside their own upload; *gave_up = those among them whose launch waited in vain for a part of the
  * batch (its upload or sort found no room on the GPU beside the launch, e.g. while other processes use it) and which
- * were then traced again chunk by chunk: the results are the same, the time is lost. Either pointer may be NULL. */
+ * were then traced again chunk by chunk: the results are the same, the time (20 ms) is lost. After the second such batch the
+ * handle stops using the one-launch path. Either pointer may be NULL. */
 int rtgi_hip_host_path_stats(const rtgi_hip_tracer *h, uint64_t *one_launch, uint64_t *gave_up);
 
 /* Page-locked host memory for the host-buffer entry points above (no counterpart in the reference). Rays and

@@ -968,6 +968,9 @@ int trace_host_streamed(rtgi_hip_tracer *h, const rtgi_ray *rays, uint32_t n, vo
 	*fell_back = gave_up != 0;
 	++h->streamed_calls;
 	h->streamed_gave_up += gave_up != 0;
+	// Two launches that waited in vain: on this GPU, in this process, the kernels beside the launch do not get to run (e.g.
+	// their stream shares a hardware queue with the launch's): no more one-launch batches on this handle.
+	if (h->streamed_gave_up >= 2) h->host_streamed = false;
 	if (clocked) {
 		fprintf(stderr, "streamed:");
 		for (uint32_t c = 0; c < n_chunks; ++c) {
