@@ -223,6 +223,7 @@ struct rtgi_hip_tracer {
 	uint32_t stream_lds_bytes = 96u << 10;  // the launch leaves LDS free for the sort kernels that run beside it
 	uint32_t stream_wait_ticks = 2000000;  // how long a wave waits for a chunk before the launch gives up (100 MHz: 20 ms)
 	uint64_t streamed_calls = 0, streamed_gave_up = 0;
+	bool stream_probed = false;  // whether the two streams of the one-launch path have been seen to run side by side
 	uint32_t *d_stream_ctl = nullptr;  // ray counters of the chunks | octant bounds of the chunks | chunks_ready | gave_up
 	// where the chunks end, as shares of the batch: the first one short (the launch begins when it is sorted), the
 	// following ones as large as the traversal of their predecessors takes the next upload and sort to complete
@@ -821,6 +822,37 @@ bool is_page_locked(const void *ptr) {
 	return attr.type == hipMemoryTypeHost;
 }
 
+// The one-launch path needs kernels of p.aux to run WHILE a kernel of p.run runs. Streams are mapped onto few hardware
+// queues, and two streams on one queue take turns: a launch there would wait for its chunks until it gives up. Tried
+// once per handle, with two one-thread kernels: one on p.run waits (1 ms at most) for a word that one on p.aux raises. If it
+// never sees the word, p.aux is replaced by a new stream (which lands on another queue) and the trial repeated, a few times.
+int probe_side_by_side(rtgi_hip_tracer *h, uint32_t *d_words, bool *ok) {
+	using namespace rtgi_dev;
+	HostPipe &p = *h->pipe;
+	*ok = false;
+	for (int attempt = 0; attempt < 6 && !*ok; ++attempt) {
+		if (attempt > 0) {
+			HIP_TRY(h, hipStreamSynchronize(p.aux));
+			HIP_TRY(h, hipStreamDestroy(p.aux));
+			p.aux = nullptr;
+			HIP_TRY(h, hipStreamCreateWithFlags(&p.aux, hipStreamNonBlocking));
+		}
+		HIP_TRY(h, hipMemsetAsync(d_words, 0, 2 * sizeof(uint32_t), p.run));
+		HIP_TRY(h, hipEventRecord(p.begun, p.run));
+		hipLaunchKernelGGL(await_word_kernel, dim3(1), dim3(64), 0, p.run, d_words, d_words + 1, 100000u);
+		HIP_TRY(h, hipStreamWaitEvent(p.aux, p.begun, 0));
+		// (RTGI_HIP_STREAM_PROBE_FAIL, for the tests: both kernels on one stream, as if the two streams shared a queue)
+		hipLaunchKernelGGL(chunk_ready_kernel, dim3(1), dim3(64), 0, getenv("RTGI_HIP_STREAM_PROBE_FAIL") ? p.run : p.aux, d_words, 1u);
+		HIP_TRY(h, hipGetLastError());
+		uint32_t seen = 0;
+		HIP_TRY(h, hipMemcpyAsync(&seen, d_words + 1, sizeof(seen), hipMemcpyDeviceToHost, p.run));
+		HIP_TRY(h, hipStreamSynchronize(p.run));
+		HIP_TRY(h, hipStreamSynchronize(p.aux));
+		*ok = seen != 0;
+	}
+	return RTGI_OK;
+}
+
 // A page-locked host batch in ONE traversal launch. The batch goes up in a few chunks of growing size; each chunk is
 // keyed and sorted on its own as soon as it has arrived (on a stream of its own, beside the traversal, which leaves
 // LDS and wave slots free for those kernels), and the launch, begun when the first chunk is ready, takes up the later
@@ -836,6 +868,15 @@ int trace_host_streamed(rtgi_hip_tracer *h, const rtgi_ray *rays, uint32_t n, vo
 	constexpr uint32_t CTL_COUNTERS = MAX_CHUNKS * 8 * COUNTER_STRIDE, CTL_BOUNDS = CTL_COUNTERS, CTL_READY = CTL_BOUNDS + MAX_CHUNKS * 16,
 	                   CTL_GAVE_UP = CTL_READY + 1, CTL_WORDS = CTL_READY + 16;
 	if (!h->d_stream_ctl) HIP_TRY(h, hipMalloc((void **)&h->d_stream_ctl, CTL_WORDS * sizeof(uint32_t)));
+	if (!h->stream_probed) {
+		bool side_by_side = false;
+		if (int rc = probe_side_by_side(h, h->d_stream_ctl, &side_by_side)) return rc;
+		h->stream_probed = true;
+		if (!side_by_side) {
+			h->host_streamed = false;  // (the ordinary way, from now on)
+			return RTGI_OK;
+		}
+	}
 	void *d_out_host = nullptr;  // the destination as the GPU sees it
 	if (!ANY && (hipHostGetDevicePointer(&d_out_host, out, 0) != hipSuccess || !d_out_host)) {
 		(void)hipGetLastError();
@@ -1194,6 +1235,7 @@ rtgi_hip_tracer *rtgi_hip_create(int device, int layout, int esc) {
 				    (const void *)&trace_kernel<0, true, true>, (const void *)&trace_kernel<1, false, false>, (const void *)&trace_kernel<1, false, true>,
 				    (const void *)&trace_kernel<1, true, false>, (const void *)&trace_kernel<1, true, true>, (const void *)&trace_kernel<2, false, false>,
 				    (const void *)&trace_kernel<2, false, true>, (const void *)&ray_keys_kernel, (const void *)&segment_bounds_kernel,
+				    (const void *)&chunk_ready_kernel, (const void *)&await_word_kernel,
 				    (const void *)&camera_rays_kernel, (const void *)&shadow_rays_kernel, (const void *)&pixel_offsets_kernel,
 				    (const void *)&bounce_count_kernel, (const void *)&scan_kernel, (const void *)&bounce_write_kernel,
 				    (const void *)&shade_primary_kernel, (const void *)&shade_local_kernel, (const void *)&shade_local_brdf_kernel,

@@ -592,6 +592,18 @@ __global__ void chunk_ready_kernel(uint32_t *chunks_ready, uint32_t value) {
 	if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(chunks_ready, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Waits up to `ticks` (100 MHz) for *word to become non-zero and stores whether it did: launched on one stream while a
+// chunk_ready_kernel on another raises the word, it tells whether kernels of the two streams can run side by side at all
+// (streams that share a hardware queue run one after the other).
+__global__ void await_word_kernel(const uint32_t *word, uint32_t *seen, uint32_t ticks) {
+	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	const unsigned long long since = __builtin_amdgcn_s_memrealtime();
+	uint32_t v = 0;
+	while ((v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0 && __builtin_amdgcn_s_memrealtime() - since < ticks)
+		__builtin_amdgcn_s_sleep(32);
+	*seen = v != 0;
+}
+
 // Positions in the sorted key array where the direction octant changes: the 8 parts of the batch that the 8
 // XCDs start on (bounds[8] = n). One wave per boundary; every step cuts the candidate range into 64 parts.
 __global__ __launch_bounds__(512) void segment_bounds_kernel(const uint32_t *sorted_keys, uint32_t n, uint32_t *bounds) {

@@ -584,3 +584,33 @@ def test_page_locked_host_batch_whose_launch_gives_up(monkeypatch):
     finally:
         L.rtgi_hip_host_free(p_rays), L.rtgi_hip_host_free(p_hits)
     t.close()
+
+
+def test_page_locked_host_batch_when_streams_cannot_run_side_by_side(monkeypatch):
+    """Before its first one-launch batch a handle tries whether a kernel on its second stream runs while one on the launch
+    stream waits for it; where it does not (streams sharing a hardware queue; here: forced), the handle never starts a
+    launch that would wait in vain, and page-locked batches are traced in chunks as before."""
+    import torch
+    monkeypatch.setenv("RTGI_HIP_STREAM_PROBE_FAIL", "1")
+    pos, tri, _ = scenes.soup(60000, seed=2, size=0.2)
+    t = tracer.HipBvhTracer(layout="indexed")
+    t.build(pos, tri)
+    n = 600000
+    rays = _mixed_rays(pos, n, seed=35)
+    d_rays = torch.from_numpy(rays).cuda()
+    d_hits = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+    t.closest_hit_device(d_rays, d_hits)
+    torch.cuda.synchronize()
+    want = d_hits.cpu().numpy().view(tracer.HIT_DTYPE).reshape(-1)
+    L = tracer.lib()
+    p_rays, _ = _page_locked_copy(rays)
+    p_hits, v_hits = _page_locked_copy(np.zeros(n, tracer.HIT_DTYPE))
+    try:
+        for _ in range(2):
+            v_hits.view(np.uint8)[...] = 0xAB
+            t._check(L.rtgi_hip_closest_hit(t._h, p_rays, n, p_hits))
+            assert_hits_equal(v_hits, want, "page-locked closest_hit, chunked")
+        assert t.host_path_stats() == dict(one_launch=0, gave_up=0)
+    finally:
+        L.rtgi_hip_host_free(p_rays), L.rtgi_hip_host_free(p_hits)
+    t.close()
