@@ -894,6 +894,7 @@ int trace_host_streamed(rtgi_hip_tracer *h, const rtgi_ray *rays, uint32_t n, vo
 		if (n_chunks == MAX_CHUNKS) --n_chunks;
 		ends[n_chunks++] = n;
 	}
+	if (n_chunks == 1) return RTGI_OK;  // (nothing to take up later: the ordinary way, *fell_back is set)
 	Scratch sc;
 	if (int rc = handle_scratch(h, n, sort, sc)) return rc;
 	const size_t cap = sc.sort_cap;

@@ -65,7 +65,12 @@ def main():
     timed(None, "on", "library sort (keys, radix sort, octant segments)")
     timed(None, "off", "caller's order, no sort")
     timed(np.argsort(key, kind="stable"), "off", "whole batch ordered by the key on the host")
-    for wsize in (1024, 4096, 8192, 32768, 131072):
+    for parts in ((0.12, 0.4, 1.0), (0.5, 1.0), (0.2, 0.4, 0.6, 0.8, 1.0)):  # the chunks of a one-launch host batch, each ordered on its own
+        ends = [int(n * f) & ~63 if f < 1.0 else n for f in parts]
+        begins = [0] + ends[:-1]
+        order = np.concatenate([b + np.argsort(key[b:e], kind="stable") for b, e in zip(begins, ends)])
+        timed(order, "off", "parts ending at %s of the batch, each ordered by the key" % (parts,))
+    for wsize in (131072, 524288):
         order = np.concatenate([s + np.argsort(key[s:s + wsize], kind="stable") for s in range(0, n, wsize)])
         timed(order, "off", "windows of %6d rays ordered by the key" % wsize)
         coarse = key >> 16  # octant | length class
