@@ -1058,7 +1058,9 @@ int trace_host(rtgi_hip_tracer *h, const rtgi_ray *rays, uint32_t n, void *out) 
 	if (rc) return rc;
 	HostPipe &p = *h->pipe;
 	const bool rays_locked = is_page_locked(rays), out_locked = is_page_locked(out);
-	if (h->host_streamed && rays_locked && out_locked && n >= h->stream_min && n < (1u << 31)) {
+	// (the kernel stores hit records as 16-byte words: a destination that is not aligned to them gets its results by a copy)
+	const bool out_aligned = ANY || (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+	if (h->host_streamed && rays_locked && out_locked && out_aligned && n >= h->stream_min && n < (1u << 31)) {
 		const bool sort = (h->reorder == 1 || (h->reorder == 2 && h->probe_pops > h->reorder_min_pops)) && n >= 4 * h->reorder_min;
 		HIP_TRY(h, hipStreamSynchronize(nullptr));  // (work that earlier calls left on the default stream comes first)
 		bool fell_back = true;
@@ -1131,7 +1133,7 @@ int trace_host(rtgi_hip_tracer *h, const rtgi_ray *rays, uint32_t n, void *out) 
 		// Hit records need no copy down: the kernel stores them (16 bytes each, once per ray) straight into the
 		// page-locked destination, which the stores reach over PCIe while the traversal goes on. (any_hit's single
 		// bytes would make as many PCIe writes for a sixteenth of the data: they come down as one copy.)
-		bool direct = !ANY && h->host_direct;
+		bool direct = !ANY && h->host_direct && (out_aligned || !out_locked);
 		if (direct) {
 			void *host = out_locked ? (void *)((char *)out + first * out_item) : p.slot_out[slot], *dev = nullptr;
 			if (hipHostGetDevicePointer(&dev, host, 0) == hipSuccess && dev)

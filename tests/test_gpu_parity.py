@@ -614,3 +614,32 @@ def test_page_locked_host_batch_when_streams_cannot_run_side_by_side(monkeypatch
     finally:
         L.rtgi_hip_host_free(p_rays), L.rtgi_hip_host_free(p_hits)
     t.close()
+
+
+@pytest.mark.parametrize("n", [3000, 700001])
+def test_page_locked_buffers_that_are_not_16_byte_aligned(n):
+    """Page-locked memory a caller registered may start anywhere: rays and hit records 4 bytes off the 16-byte grid are
+    traced like any others (the results then come down by a copy instead of being stored by the kernel)."""
+    import ctypes
+    pos, tri, _ = scenes.soup(20000, seed=8, size=0.3)
+    t = tracer.HipBvhTracer(layout="flat")
+    t.build(pos, tri)
+    rays = _mixed_rays(pos, n, seed=36)
+    want = t.closest_hit(rays)
+    want_any = t.any_hit(rays)
+    L = tracer.lib()
+    p_rays, p_hits, p_occ = L.rtgi_hip_host_alloc(rays.nbytes + 16), L.rtgi_hip_host_alloc(n * 16 + 16), L.rtgi_hip_host_alloc(n + 16)
+    assert p_rays and p_hits and p_occ
+    try:
+        ctypes.memmove(p_rays + 4, rays.ctypes.data, rays.nbytes)
+        ctypes.memset(p_hits, 0xAB, n * 16 + 16)
+        t._check(L.rtgi_hip_closest_hit(t._h, p_rays + 4, n, p_hits + 4))
+        got = np.frombuffer(ctypes.string_at(p_hits + 4, n * 16), dtype=tracer.HIT_DTYPE)
+        assert_hits_equal(got, want, "unaligned page-locked closest_hit")
+        assert ctypes.string_at(p_hits, 4) == b"\xab" * 4 and ctypes.string_at(p_hits + 4 + n * 16, 12) == b"\xab" * 12
+        t._check(L.rtgi_hip_any_hit(t._h, p_rays + 4, n, p_occ + 3))
+        assert np.array_equal(np.frombuffer(ctypes.string_at(p_occ + 3, n), dtype=np.uint8), want_any)
+    finally:
+        for ptr in (p_rays, p_hits, p_occ):
+            L.rtgi_hip_host_free(ptr)
+    t.close()
