@@ -223,6 +223,11 @@ struct rtgi_hip_tracer {
 	uint32_t stream_lds_bytes = 96u << 10;  // the launch leaves LDS free for the sort kernels that run beside it
 	uint32_t stream_wait_ticks = 2000000;  // how long a wave waits for a chunk before the launch gives up (100 MHz: 20 ms)
 	uint64_t streamed_calls = 0, streamed_gave_up = 0;
+	// rays this handle last wrote as camera rays (rtgi_hip_camera_rays*_device): neighbours in the buffer are neighbours in
+	// the image and share their origin, which "reorder auto" does not sort
+	const void *camera_rays_at = nullptr;
+	uint32_t camera_rays_n = 0;
+	uint64_t launches = 0, launches_sorted = 0;
 	bool stream_probed = false;  // whether the two streams of the one-launch path have been seen to run side by side
 	uint32_t *d_stream_ctl = nullptr;  // ray counters of the chunks | octant bounds of the chunks | chunks_ready | gave_up
 	// where the chunks end, as shares of the batch: the first one short (the launch begins when it is sorted), the
@@ -619,7 +624,9 @@ int launch_batches(rtgi_hip_tracer *h, const BatchView *given, uint32_t n_given,
 	ScratchTurn turn{h, stream};
 	if (!fixed)  // (launches in fixed scratch are ordered by their callers)
 		if (int rc = turn.begin()) return rc;
-	bool sort = (h->reorder == 1 || (h->reorder == 2 && h->probe_pops > h->reorder_min_pops)) && n >= h->reorder_min &&
+	// (auto: not for a batch that this handle itself filled with camera rays, which are in image order)
+	const bool camera_batch = n_batches == 1 && batches[0].rays == h->camera_rays_at && n == h->camera_rays_n;
+	bool sort = (h->reorder == 1 || (h->reorder == 2 && h->probe_pops > h->reorder_min_pops && !camera_batch)) && n >= h->reorder_min &&
 	            n < (1u << 31);  // (the sort counts in int)
 	Scratch sc;
 	if (fixed) {
@@ -703,6 +710,8 @@ int launch_batches(rtgi_hip_tracer *h, const BatchView *given, uint32_t n_given,
 	a.spill_stride = blocks * BLOCK;
 	a.order = nullptr;
 	a.seg_bounds = nullptr;
+	++h->launches;
+	h->launches_sorted += sort;
 	if (sort) {
 		int rc = sort_rays(h, batches, n_batches, n, sc, stream, &a.order);
 		if (rc) return rc;
@@ -1658,6 +1667,8 @@ int camera_rays(rtgi_hip_tracer *h, const rtgi_camera *cam, const uint32_t *d_pi
 	a.n = n;
 	hipLaunchKernelGGL(rtgi_dev::camera_rays_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
 	HIP_TRY(h, hipGetLastError());
+	h->camera_rays_at = d_rays;
+	h->camera_rays_n = n;
 	return RTGI_OK;
 }
 }  // namespace
@@ -1797,6 +1808,7 @@ int rtgi_hip_shadow_rays_device(rtgi_hip_tracer *h, const rtgi_hit *d_hits, uint
 	a.n = n;
 	hipLaunchKernelGGL(rtgi_dev::shadow_rays_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
 	HIP_TRY(h, hipGetLastError());
+	if (d_shadow == h->camera_rays_at) h->camera_rays_at = nullptr;  // (that buffer holds other rays now)
 	return RTGI_OK;
 }
 
@@ -2056,6 +2068,7 @@ int rtgi_hip_bounce_rays_keyed_device(rtgi_hip_tracer *h, const rtgi_ray *d_rays
 		HIP_TRY(h, hipMalloc((void **)&h->d_block_counts, (size_t)n_blocks * sizeof(uint32_t)));
 		h->block_counts_cap = n_blocks;
 	}
+	if (d_out == h->camera_rays_at) h->camera_rays_at = nullptr;  // (that buffer holds other rays now)
 	rtgi_dev::BounceArgs a;
 	a.rays = (const float4 *)d_rays;
 	a.hits = (const float4 *)d_hits;
@@ -2095,6 +2108,13 @@ int rtgi_hip_profile_work(rtgi_hip_tracer *h, uint64_t out[4]) {
 	unsigned long long v[4];
 	HIP_TRY(h, hipMemcpy(v, h->d_totals, sizeof(v), hipMemcpyDeviceToHost));
 	for (int k = 0; k < 4; ++k) out[k] = v[k];
+	return RTGI_OK;
+}
+
+int rtgi_hip_launch_stats(const rtgi_hip_tracer *h, uint64_t *launches, uint64_t *sorted) {
+	if (!h) return RTGI_ERR_INVALID;
+	if (launches) *launches = h->launches;
+	if (sorted) *sorted = h->launches_sorted;
 	return RTGI_OK;
 }
 

@@ -35,7 +35,7 @@ EXPORTS = [
     "rtgi_hip_framebuffer_scatter_device", "rtgi_hip_framebuffer_sums_device", "rtgi_hip_framebuffer_accumulate_device", "rtgi_hip_shadow_rays_device", "rtgi_hip_bounce_rays_device", "rtgi_hip_set_shading",
     "rtgi_hip_shade_primary_device", "rtgi_hip_shade_local_device", "rtgi_hip_set_materials", "rtgi_hip_set_textures", "rtgi_hip_shade_local_brdf_device", "rtgi_hip_framebuffer_add_device",
     "rtgi_hip_framebuffer_rgb8_device", "rtgi_hip_profile_begin", "rtgi_hip_profile_end", "rtgi_hip_profile_work", "rtgi_hip_profile_details",
-    "rtgi_hip_host_path_stats",
+    "rtgi_hip_host_path_stats", "rtgi_hip_launch_stats",
     "rtgi_hip_last_error",
 ]
 
@@ -119,6 +119,7 @@ def lib():
         L.rtgi_hip_profile_work.argtypes = [vp, vp]
         L.rtgi_hip_profile_details.argtypes = [vp, vp, vp, vp, vp]
         L.rtgi_hip_host_path_stats.argtypes = [vp, vp, vp]
+        L.rtgi_hip_launch_stats.argtypes = [vp, vp, vp]
         L.rtgi_hip_last_error.argtypes = [vp]
         L.rtgi_hip_last_error.restype = cp
         _lib = L
@@ -411,6 +412,12 @@ class HipBvhTracer:
         pushes, links, lds, spill = C.c_uint64(0), C.c_uint64(0), C.c_uint32(0), C.c_uint32(0)
         self._check(lib().rtgi_hip_profile_details(self._h, C.byref(pushes), C.byref(links), C.byref(lds), C.byref(spill)))
         return dict(spill_pushes=pushes.value, link_fetches=links.value, lds_levels=lds.value, spill_levels=spill.value)
+
+    def launch_stats(self):
+        """dict(launches, sorted): traversal launches on this handle so far, and those that traced their rays in sorted order."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._check(lib().rtgi_hip_launch_stats(self._h, C.byref(a), C.byref(b)))
+        return dict(launches=a.value, sorted=b.value)
 
     def host_path_stats(self):
         """dict(one_launch, gave_up): page-locked host batches traced by one launch beside their own upload, and those

@@ -127,3 +127,41 @@ def test_bounce_rays_and_compaction():
     t.closest_hit_device(d_far, d_hits)
     empty, _ = t.bounce_rays_device(d_far, d_hits)
     assert empty.shape[0] == 0
+
+
+def test_reorder_auto_leaves_camera_rays_in_image_order():
+    """On a scene whose incoherent rays are expensive "reorder auto" sorts batches, except one that the handle's own camera
+    ray stage has just written: those rays lie in image order already. The results are the same either way; what was
+    sorted shows in the launch statistics."""
+    import torch
+    pos, tri, _ = scenes.soup(1 << 20, seed=1)
+    t = tracer.HipBvhTracer(layout="flat")
+    t.build(pos, tri)
+    assert t.incoherent_ray_cost > 120                      # auto sorts on this scene
+    cam = (np.array([0, 0, -1], np.float32), [0, 0, 0], [0, 1, 0], 65.0, 640, 360)
+    d_rays = t.camera_rays_device(*cam)
+    n = d_rays.shape[0]
+    d_hits = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+    before = t.launch_stats()
+    t.closest_hit_device(d_rays, d_hits)                    # the batch just written: not sorted
+    after = t.launch_stats()
+    assert (after["launches"] - before["launches"], after["sorted"] - before["sorted"]) == (1, 0)
+    copy = d_rays.clone()
+    d_hits2 = torch.empty_like(d_hits)
+    t.closest_hit_device(copy, d_hits2)                     # the same rays from another buffer: sorted
+    assert t.launch_stats()["sorted"] - after["sorted"] == 1
+    assert torch.equal(d_hits, d_hits2)
+    d_bounce, _ = t.bounce_rays_device(d_rays, d_hits, seed=1, bounce=1)
+    d_shadow = t.shadow_rays_device(d_hits, [1.0, 5.0, 2.0])
+    d_occ = torch.empty(n, dtype=torch.uint8, device="cuda")
+    s0 = t.launch_stats()["sorted"]
+    t.any_hit_device(d_shadow, d_occ)                       # shadow rays (n of them, too): sorted
+    assert t.launch_stats()["sorted"] - s0 == 1
+    assert t.interprete("hip", "reorder on")
+    s0 = t.launch_stats()["sorted"]
+    t.closest_hit_device(d_rays, d_hits2)                   # "on" sorts whatever the batch is
+    assert t.launch_stats()["sorted"] - s0 == 1 and torch.equal(d_hits, d_hits2)
+    o = orc.Bbvh(pos, tri, layout="flat")
+    sample = np.arange(0, n, 7)
+    assert_hits_equal(_hits_of(d_hits)[sample], o.closest_hit(d_rays.cpu().numpy()[sample]), "camera rays, image order")
+    t.close()
