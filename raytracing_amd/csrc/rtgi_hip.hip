@@ -202,6 +202,7 @@ struct rtgi_hip_tracer {
 	uint32_t blocks_per_cu = 1;
 	// division of a workgroup's LDS (set at upload from the tree's depth and size, see trace_kernel.h)
 	uint32_t stack_levels = 1, top_nodes = 0, lds_bytes = 0, implicit_limit = 0;
+	bool boxes_ordered = false;  // every child box has min <= max on every axis: octant-pure waves skip the min / max of the slab test
 	int force_stack_levels = 0, max_top_nodes = 1 << 30;
 	uint32_t n_segments = 8;
 	int32_t *d_spill = nullptr;
@@ -397,6 +398,11 @@ int upload_flat(rtgi_hip_tracer *h, const rtgi::FlatTree &flat, const rtgi::Scen
 		h->scene_inv_extent[k] = hi[k] > lo[k] ? 1.0f / (hi[k] - lo[k]) : 0.0f;
 	}
 	h->root_ref = flat.root_ref;
+	// node record: l.min.x r.min.x l.min.y r.min.y l.min.z r.min.z | the six max planes in the same order | links
+	h->boxes_ordered = !getenv("RTGI_HIP_NO_OCTANT_WAVES");
+	for (size_t i = 0; h->boxes_ordered && i + 16 <= flat.nodes.size(); i += 16)
+		for (int k = 0; k < 6; ++k)
+			if (!(flat.nodes[i + k] <= flat.nodes[i + 6 + k])) h->boxes_ordered = false;
 	h->n_scene_triangles = scene.n_triangles;
 	h->n_scene_vertices = scene.n_vertices;
 	h->built = true;
@@ -687,8 +693,8 @@ int launch_batches(rtgi_hip_tracer *h, const BatchView *given, uint32_t n_given,
 		HIP_TRY(h, hipMemcpy(v, d_diag, 128, hipMemcpyDeviceToHost));
 		HIP_TRY(h, diag_reset());
 		if (v[7])
-			fprintf(stderr, "diag(prev launch): inner iters fed %llu (%.1f%% lanes) | dry %llu (%.1f%% lanes) | refills %llu outer %llu | wall %.3f ms, supply dry at %.3f..%.3f ms, mean wave life %.3f ms\n",
-			        v[0], v[0] ? 100.0 * v[1] / (64.0 * v[0]) : 0.0, v[2], v[2] ? 100.0 * v[3] / (64.0 * v[2]) : 0.0, v[6], v[7],
+			fprintf(stderr, "diag(prev launch): inner iters fed %llu (%.1f%% lanes) | dry %llu (%.1f%% lanes) | leaf iters %llu (%.1f%% lanes) | refills %llu outer %llu | wall %.3f ms, supply dry at %.3f..%.3f ms, mean wave life %.3f ms\n",
+			        v[0], v[0] ? 100.0 * v[1] / (64.0 * v[0]) : 0.0, v[2], v[2] ? 100.0 * v[3] / (64.0 * v[2]) : 0.0, v[4], v[4] ? 100.0 * v[5] / (64.0 * v[4]) : 0.0, v[6], v[7],
 			        (v[9] - v[8]) * 1e-5, (v[10] - v[8]) * 1e-5, (v[11] - v[8]) * 1e-5, v[12] * 1e-5 / (double)(h->grid_blocks * (BLOCK / 64)));
 	}
 #endif
@@ -697,6 +703,7 @@ int launch_batches(rtgi_hip_tracer *h, const BatchView *given, uint32_t n_given,
 	a.drain_leaf_min = h->drain_leaf_min;
 	a.top_nodes = (int32_t)h->top_nodes;
 	a.implicit_limit = (int32_t)h->implicit_limit;
+	a.boxes_ordered = h->boxes_ordered ? 1 : 0;
 	a.stack_levels = (int32_t)h->stack_levels;
 	// (a small batch still spreads over the CUs: a workgroup per 256 rays, its other waves find the supply dry at once)
 	uint32_t blocks = (n + 255) / 256;
@@ -990,6 +997,7 @@ int trace_host_streamed(rtgi_hip_tracer *h, const rtgi_ray *rays, uint32_t n, vo
 	a.leaf_min = h->leaf_min;
 	a.drain_leaf_min = h->drain_leaf_min;
 	a.implicit_limit = (int32_t)h->implicit_limit;
+	a.boxes_ordered = h->boxes_ordered ? 1 : 0;
 	a.stack_levels = (int32_t)h->stack_levels;
 	a.n_chunks = n_chunks;
 	a.chunks_ready = h->d_stream_ctl + CTL_READY;

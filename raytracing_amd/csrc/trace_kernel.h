@@ -99,6 +99,8 @@ struct TraceArgs {
 	int32_t top_nodes;      // visits to inner nodes 0 .. top_nodes-1 are served from a copy in LDS
 	int32_t stack_levels;   // pending-node slots per lane in LDS; dynamic LDS: see lds_bytes_for()
 	int32_t implicit_limit; // inner nodes below this index are numbered like a heap: children 2i and 2i + 1, no link fetch
+	int32_t boxes_ordered;  // every child box of the tree has min <= max on every axis (checked at upload): waves whose rays
+	                        // share a direction octant take the near and far planes by position instead of by min / max
 #ifdef RTGI_DIAG
 	unsigned long long *diag;  // diagnostic build only: 8 counters summed over all waves
 #endif
@@ -360,8 +362,9 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void trace_kernel(TraceArgs 
 		const int leave = __builtin_amdgcn_readfirstlane(more ? a.leaf_min : a.drain_leaf_min);
 
 		// one step of one lane: the two child boxes of its node against its ray; which ones to enter, and which one first
-		auto boxes = [&](auto plain_tag, const u32x4 q0, const u32x4 q1, const u32x4 q2, bool &hl, bool &hr, bool &left_first) {
+		auto boxes = [&](auto plain_tag, auto octant_tag, const u32x4 q0, const u32x4 q1, const u32x4 q2, bool &hl, bool &hr, bool &left_first) {
 			constexpr bool PLAIN = decltype(plain_tag)::value;
+			constexpr int OCT = decltype(octant_tag)::value;  // 0..7: signs of the direction of every ray of the wave; -1: mixed
 			if (COUNT) ++n_inner;
 			auto pair = [](uint32_t u, uint32_t v) { return f32x2{__uint_as_float(u), __uint_as_float(v)}; };
 			// .x = left child, .y = right child; (box - o) * id as in libgi/intersect.h:210-221
@@ -372,7 +375,22 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void trace_kernel(TraceArgs 
 			const f32x2 by = (pair(q2.x, q2.y) - f32x2{oy, oy}) * f32x2{iy, iy};
 			const f32x2 bz = (pair(q2.z, q2.w) - f32x2{oz, oz}) * f32x2{iz, iz};
 			float dl, dr;
-			if (PLAIN) {
+			if (PLAIN && OCT >= 0) {
+				// All rays of the wave look the same way along every axis. For a box with min <= max and a positive inverse
+				// direction, (min - o) * id <= (max - o) * id holds after rounding too (subtraction and multiplication by a
+				// positive number are monotonic), so the smaller product of intersect.h:212-217 is the min plane's, and the max
+				// plane's for a negative inverse direction: the twelve min / max of the general case are not needed. (Where the
+				// two products are equal they may differ in the sign of a zero, which no comparison below sees.)
+				const f32x2 nx = (OCT & 1) ? bx : ax, fx = (OCT & 1) ? ax : bx;
+				const f32x2 ny = (OCT & 2) ? by : ay, fy = (OCT & 2) ? ay : by;
+				const f32x2 nz = (OCT & 4) ? bz : az, fz = (OCT & 4) ? az : bz;
+				dl = vmax3(nx.x, ny.x, nz.x);
+				dr = vmax3(nx.y, ny.y, nz.y);
+				const float fl = vmin3(fx.x, fy.x, fz.x);
+				const float fr = vmin3(fx.y, fy.y, fz.y);
+				hl = (vmax(dl, t_min) <= fl) && (dl < lim);
+				hr = (vmax(dr, t_min) <= fr) && (dr < lim);
+			} else if (PLAIN) {
 				// no NaN possible: the selects of intersect.h:212-228 are exact min / max, and
 				// !(t1 > t2) && !(t2 < t_min) && !(t1 > t_max) [&& t1 < closest t] folds into two compares
 				dl = vmax3(vmin(ax.x, bx.x), vmin(ay.x, by.x), vmin(az.x, bz.x));
@@ -425,7 +443,7 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void trace_kernel(TraceArgs 
 
 		// ---- inner nodes: every lane standing on an inner node takes one step per iteration; the loop ends once `leave`
 		// lanes have left it (reached a leaf or finished their ray), or nobody is left -----------------------------------
-		auto inner_phase = [&](auto plain_tag) {
+		auto inner_phase = [&](auto plain_tag, auto octant_tag) {
 			const int keep_going = max(0, n_busy - leave);
 			// (the count of lanes on inner nodes is wave-uniform and carried from the end of one iteration to the next)
 			for (unsigned long long on_inner = __ballot(cur >= 0); (int)__popcll(on_inner) > keep_going; on_inner = __ballot(cur >= 0)) {
@@ -439,7 +457,7 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void trace_kernel(TraceArgs 
 					u32x2 links = u32x2{(uint32_t)cur << 1, ((uint32_t)cur << 1) | 1u};  // heap-numbered nodes: no link fetch
 					fetch(cur >= implicit_limit, q0, q1, q2, links);
 					bool hl, hr, left_first;
-					boxes(plain_tag, q0, q1, q2, hl, hr, left_first);
+					boxes(plain_tag, octant_tag, q0, q1, q2, hl, hr, left_first);
 					const int32_t first = (int32_t)(left_first ? links.x : links.y);
 					const int32_t second = (int32_t)(left_first ? links.y : links.x);
 					if (hl && hr) push(second);
@@ -450,10 +468,27 @@ __global__ __launch_bounds__(BLOCK, WAVES_PER_SIMD) void trace_kernel(TraceArgs 
 				}
 			}
 		};
-		if (wave_plain)
-			inner_phase(std::true_type{});
+		// Sorted batches hand a wave rays of one direction octant (and so do neighbouring camera rays): is that so now?
+		int octant = -1;
+		if (wave_plain && a.boxes_ordered) {
+			const unsigned long long neg_x = __ballot(ix < 0.0f) & busy, neg_y = __ballot(iy < 0.0f) & busy, neg_z = __ballot(iz < 0.0f) & busy;
+			if ((neg_x == 0 || neg_x == busy) && (neg_y == 0 || neg_y == busy) && (neg_z == 0 || neg_z == busy))
+				octant = (neg_x ? 1 : 0) | (neg_y ? 2 : 0) | (neg_z ? 4 : 0);
+		}
+		if (!wave_plain)
+			inner_phase(std::false_type{}, std::integral_constant<int, -1>{});
 		else
-			inner_phase(std::false_type{});
+			switch (octant) {
+			case 0: inner_phase(std::true_type{}, std::integral_constant<int, 0>{}); break;
+			case 1: inner_phase(std::true_type{}, std::integral_constant<int, 1>{}); break;
+			case 2: inner_phase(std::true_type{}, std::integral_constant<int, 2>{}); break;
+			case 3: inner_phase(std::true_type{}, std::integral_constant<int, 3>{}); break;
+			case 4: inner_phase(std::true_type{}, std::integral_constant<int, 4>{}); break;
+			case 5: inner_phase(std::true_type{}, std::integral_constant<int, 5>{}); break;
+			case 6: inner_phase(std::true_type{}, std::integral_constant<int, 6>{}); break;
+			case 7: inner_phase(std::true_type{}, std::integral_constant<int, 7>{}); break;
+			default: inner_phase(std::true_type{}, std::integral_constant<int, -1>{}); break;
+			}
 
 		// ---- leaves: all triangles of the leaf, in slot order ---------------------------------------------
 		if (cur < 0 && cur != IDLE) {

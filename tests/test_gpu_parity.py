@@ -242,6 +242,50 @@ def test_upload_of_a_foreign_tree():
     assert_hits_equal(t.closest_hit(rays), o.closest_hit(rays), "uploaded tree")
 
 
+def test_waves_of_one_direction_octant(monkeypatch):
+    # Waves whose rays all look the same way along every axis take the near and far planes of a box by position
+    # instead of by min / max (sorted batches and neighbouring camera rays make such waves). That is only exact for
+    # boxes with min <= max: a tree from outside with a box turned inside out must fall back to the general test,
+    # which treats it like the box it mirrors (intersect.h:212-217 selects by comparing the products).
+    pos, tri, _ = scenes.soup(30000, seed=16, size=0.3)
+    o = orc.Bbvh(pos, tri, layout="indexed")
+    rng = np.random.default_rng(3)
+    rays = scenes.random_rays(200000, seed=33)
+    for octant in range(8):  # 8192 rays per octant on purpose: whole waves of each
+        part = rays[octant * 8192:(octant + 1) * 8192]
+        for k in range(3):
+            part[:, 3 + k] = np.abs(part[:, 3 + k]) * (-1.0 if (octant >> k) & 1 else 1.0)
+    want, want_counts = o.closest_hit(rays, counts=True)
+    want_any, want_any_counts = o.any_hit(rays, counts=True)
+    t = tracer.HipBvhTracer(layout="indexed")
+    t.build(pos, tri)
+    for mode in ("off", "on"):
+        assert t.interprete("hip", "reorder " + mode)
+        assert_hits_equal(t.closest_hit(rays), want, "octant waves, reorder " + mode)
+        _check_device_path(t, rays, want, want_counts, want_any, want_any_counts)
+    # the same tree with some boxes turned inside out along one axis
+    nodes = o.nodes().copy()
+    inner = np.flatnonzero(nodes["link_r"] >= 0)
+    for i in rng.choice(inner, 200, replace=False):
+        box = nodes["box_l" if i & 1 else "box_r"][i]
+        k = int(i) % 3
+        box[k], box[3 + k] = box[3 + k], box[k]
+    results = []
+    for general_only in (True, False):
+        if general_only:
+            monkeypatch.setenv("RTGI_HIP_NO_OCTANT_WAVES", "1")
+        else:
+            monkeypatch.delenv("RTGI_HIP_NO_OCTANT_WAVES")
+        u = tracer.HipBvhTracer(layout="indexed")
+        u.upload_bvh(nodes, o.root, o.index(), pos, tri)
+        assert u.interprete("hip", "reorder on")
+        results.append((u.closest_hit(rays), u.any_hit(rays)))
+    assert_hits_equal(results[1][0], results[0][0], "inside-out boxes")
+    assert (results[1][1] == results[0][1]).all()
+    # (min / max do not see which plane was called min: the mirrored boxes give the original tree's hits)
+    assert_hits_equal(results[0][0], want, "inside-out boxes against the oracle's tree")
+
+
 def test_full_size_soup_properties():
     # benchmark-size scene (2^20 triangles): oracle on a sample, size-independent properties on the rest
     import torch
