@@ -220,6 +220,7 @@ struct rtgi_hip_tracer {
 	HostPipe *pipe = nullptr;
 	// page-locked host batches in ONE launch that takes up the later chunks as their upload and sort complete
 	bool host_streamed = true;
+	bool stream_coarse = true;         // chunks of such a batch are ordered by octant and length class only (two kernels instead of the sort's eight)
 	uint32_t stream_min = 1u << 19;    // batches of at least this many rays
 	uint32_t stream_lds_bytes = 96u << 10;  // the launch leaves LDS free for the sort kernels that run beside it
 	uint32_t stream_wait_ticks = 2000000;  // how long a wave waits for a chunk before the launch gives up (100 MHz: 20 ms)
@@ -319,6 +320,7 @@ void read_tunables(rtgi_hip_tracer *h) {
 	h->host_lead = (uint32_t)number("RTGI_HIP_HOST_LEAD", 0, 1 << 30, (int)h->host_lead);
 	h->host_direct = number("RTGI_HIP_HOST_DIRECT", 0, 1, 1) != 0;
 	h->host_streamed = number("RTGI_HIP_HOST_STREAMED", 0, 1, 1) != 0;
+	h->stream_coarse = number("RTGI_HIP_STREAM_COARSE", 0, 1, h->stream_coarse ? 1 : 0) != 0;
 	h->stream_min = (uint32_t)number("RTGI_HIP_STREAM_MIN", 1 << 16, 1 << 30, (int)h->stream_min);
 	h->stream_lds_bytes = (uint32_t)number("RTGI_HIP_STREAM_LDS_KIB", 16, 160, (int)(h->stream_lds_bytes >> 10)) << 10;
 	h->stream_wait_ticks = (uint32_t)number("RTGI_HIP_STREAM_WAIT_TICKS", 1, 1 << 30, (int)h->stream_wait_ticks);
@@ -882,7 +884,8 @@ int trace_host_streamed(rtgi_hip_tracer *h, const rtgi_ray *rays, uint32_t n, vo
 	*fell_back = true;
 	HostPipe &p = *h->pipe;
 	constexpr uint32_t CTL_COUNTERS = MAX_CHUNKS * 8 * COUNTER_STRIDE, CTL_BOUNDS = CTL_COUNTERS, CTL_READY = CTL_BOUNDS + MAX_CHUNKS * 16,
-	                   CTL_GAVE_UP = CTL_READY + 1, CTL_WORDS = CTL_READY + 16;
+	                   CTL_GAVE_UP = CTL_READY + 1, CTL_COARSE = CTL_READY + 16, COARSE_WORDS = 2 * COARSE_BINS + 16,  // per chunk: counts | cursors | done
+	                   CTL_WORDS = CTL_COARSE + MAX_CHUNKS * COARSE_WORDS;
 	if (!h->d_stream_ctl) HIP_TRY(h, hipMalloc((void **)&h->d_stream_ctl, CTL_WORDS * sizeof(uint32_t)));
 	if (!h->stream_probed) {
 		bool side_by_side = false;
@@ -914,7 +917,8 @@ int trace_host_streamed(rtgi_hip_tracer *h, const rtgi_ray *rays, uint32_t n, vo
 	Scratch sc;
 	if (int rc = handle_scratch(h, n, sort, sc)) return rc;
 	const size_t cap = sc.sort_cap;
-	if (sort) {  // the sort's own scratch must hold for every chunk's size (the library picks its algorithm by size)
+	const bool coarse = sort && h->stream_coarse;
+	if (sort && !coarse) {  // the sort's own scratch must hold for every chunk's size (the library picks its algorithm by size)
 		size_t need = 0;
 		for (uint32_t c = 0; c < n_chunks; ++c) {
 			size_t temp = 0;
@@ -956,7 +960,24 @@ int trace_host_streamed(rtgi_hip_tracer *h, const rtgi_ray *rays, uint32_t n, vo
 		HIP_TRY(h, hipEventRecord(p.chunk_up[c], p.up));
 		HIP_TRY(h, hipStreamWaitEvent(p.aux, p.chunk_up[c], 0));
 		a.chunk_end[c] = ends[c];
-		if (sort) {
+		if (coarse) {
+			// two kernels: bin of every ray and the bins' counts; then the rays bin after bin. The second one's last workgroup
+			// announces the chunk.
+			k.rays = (const float4 *)(d_rays + begin);
+			k.keys = nullptr, k.index = nullptr;
+			k.n = count;
+			k.first = 0;
+			k.index_base = begin;
+			uint8_t *bins = reinterpret_cast<uint8_t *>(sc.sort) + begin;
+			uint32_t *order = sc.sort + 2 * cap;
+			uint32_t *ctl = h->d_stream_ctl + CTL_COARSE + c * COARSE_WORDS, *bounds = h->d_stream_ctl + CTL_BOUNDS + c * 16;
+			const uint32_t tiles = (count + COARSE_TILE - 1) / COARSE_TILE;
+			hipLaunchKernelGGL(ray_bins_kernel, dim3(tiles), dim3(COARSE_BLOCK), 0, p.aux, k, bins, ctl);
+			hipLaunchKernelGGL(coarse_scatter_kernel, dim3(tiles), dim3(COARSE_BLOCK), 0, p.aux, (const uint8_t *)bins, count, begin, (const uint32_t *)ctl,
+			                   ctl + COARSE_BINS, order + begin, bounds, ctl + 2 * COARSE_BINS, h->d_stream_ctl + CTL_READY, c + 1);
+			a.chunk_order[c] = order;  // (indexed by the position in the whole batch)
+			a.chunk_bounds[c] = bounds;
+		} else if (sort) {
 			// this chunk's part of the four sort arrays; which of each pair holds the result is known when the call returns
 			hipcub::DoubleBuffer<uint32_t> keys(sc.sort + begin, sc.sort + cap + begin), index(sc.sort + 2 * cap + begin, sc.sort + 3 * cap + begin);
 			k.rays = (const float4 *)(d_rays + begin);
@@ -974,7 +995,7 @@ int trace_host_streamed(rtgi_hip_tracer *h, const rtgi_ray *rays, uint32_t n, vo
 			a.chunk_order[c] = index.Current() - begin;  // (indexed by the position in the whole batch)
 			a.chunk_bounds[c] = bounds;
 		}
-		hipLaunchKernelGGL(chunk_ready_kernel, dim3(1), dim3(64), 0, p.aux, h->d_stream_ctl + CTL_READY, c + 1);
+		if (!coarse) hipLaunchKernelGGL(chunk_ready_kernel, dim3(1), dim3(64), 0, p.aux, h->d_stream_ctl + CTL_READY, c + 1);
 		HIP_TRY(h, hipGetLastError());
 		if (clocked) (void)hipEventRecord(p.clock_ready[c], p.aux), (void)hipEventRecord(p.clock_up[c], p.up);
 		if (c == 0) HIP_TRY(h, hipEventRecord(p.first_ready, p.aux));
@@ -1255,7 +1276,7 @@ rtgi_hip_tracer *rtgi_hip_create(int device, int layout, int esc) {
 				    (const void *)&trace_kernel<0, true, true>, (const void *)&trace_kernel<1, false, false>, (const void *)&trace_kernel<1, false, true>,
 				    (const void *)&trace_kernel<1, true, false>, (const void *)&trace_kernel<1, true, true>, (const void *)&trace_kernel<2, false, false>,
 				    (const void *)&trace_kernel<2, false, true>, (const void *)&ray_keys_kernel, (const void *)&segment_bounds_kernel,
-				    (const void *)&chunk_ready_kernel, (const void *)&await_word_kernel,
+				    (const void *)&chunk_ready_kernel, (const void *)&await_word_kernel, (const void *)&ray_bins_kernel, (const void *)&coarse_scatter_kernel,
 				    (const void *)&camera_rays_kernel, (const void *)&shadow_rays_kernel, (const void *)&pixel_offsets_kernel,
 				    (const void *)&bounce_count_kernel, (const void *)&scan_kernel, (const void *)&bounce_write_kernel,
 				    (const void *)&shade_primary_kernel, (const void *)&shade_local_kernel, (const void *)&shade_local_brdf_kernel,

@@ -601,10 +601,7 @@ __device__ __forceinline__ float ray_span(const KeyArgs &a, const float4 q0, con
 	return t_out - t_in;
 }
 
-__global__ __launch_bounds__(256) void ray_keys_kernel(KeyArgs a) {
-	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-	if (i >= a.n) return;
-	const float4 q0 = a.rays[2 * (size_t)i], q1 = a.rays[2 * (size_t)i + 1];
+__device__ __forceinline__ uint32_t ray_key(const KeyArgs &a, const float4 q0, const float4 q1) {
 	auto cell = [](float x, float lo, float inv) {
 		const float f = (x - lo) * inv * 64.0f;
 		return (uint32_t)__builtin_fminf(__builtin_fmaxf(f == f ? f : 0.0f, 0.0f), 63.0f);
@@ -617,8 +614,78 @@ __global__ __launch_bounds__(256) void ray_keys_kernel(KeyArgs a) {
 	constexpr float top = (float)((1u << CLASS_BITS) - 1u);
 	const float rel = ray_span(a, q0, q1) * a.inv_diagonal * (top + 1.0f);
 	const uint32_t cls = (uint32_t)top - (uint32_t)__builtin_fminf(__builtin_fmaxf(rel == rel ? rel : 0.0f, 0.0f), top);
-	a.keys[a.first + i] = (octant << 21) | (cls << (21 - CLASS_BITS)) | (morton >> (CLASS_BITS - 3));
+	return (octant << 21) | (cls << (21 - CLASS_BITS)) | (morton >> (CLASS_BITS - 3));
+}
+
+__global__ __launch_bounds__(256) void ray_keys_kernel(KeyArgs a) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= a.n) return;
+	a.keys[a.first + i] = ray_key(a, a.rays[2 * (size_t)i], a.rays[2 * (size_t)i + 1]);
 	a.index[a.first + i] = a.index_base + a.first + i;
+}
+
+// ---- ordering a chunk of a host batch beside a running traversal -------------------------------------------------
+// A chunk that arrives while the launch runs is wanted soon, and every kernel started beside the launch waits tens of
+// microseconds for its turn whatever its size; the radix sort's chain of eight is most of a chunk's delay. Such a chunk is
+// ordered by the upper eight bits of the key only - direction octant and length class, 256 bins, in which rays keep the
+// caller's order roughly (tile by tile) - in two kernels: bins and their counts; places by one LDS counter per bin and
+// tile plus one global counter per bin. Inside windows of the size of a chunk this order traces 3 % slower than the full
+// key's; the last workgroup to finish announces the chunk.
+constexpr int COARSE_BINS = 256;
+constexpr int COARSE_BLOCK = 256;  // (small workgroups: they have to fit into what the traversal launch leaves of every CU)
+constexpr int COARSE_TILE = 16 * COARSE_BLOCK;  // rays per workgroup
+__global__ __launch_bounds__(COARSE_BLOCK) void ray_bins_kernel(KeyArgs a, uint8_t *bins, uint32_t *hist) {
+	__shared__ uint32_t s_hist[COARSE_BINS];
+	s_hist[threadIdx.x] = 0;
+	__syncthreads();
+	const uint32_t tile = blockIdx.x * COARSE_TILE;
+	for (uint32_t j = 0; j < COARSE_TILE; j += COARSE_BLOCK) {
+		const uint32_t i = tile + j + threadIdx.x;
+		if (i < a.n) {
+			const uint32_t bin = ray_key(a, a.rays[2 * (size_t)i], a.rays[2 * (size_t)i + 1]) >> (KEY_BITS - 8);
+			bins[i] = (uint8_t)bin;
+			atomicAdd(&s_hist[bin], 1u);
+		}
+	}
+	__syncthreads();
+	if (s_hist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_hist[threadIdx.x]);
+}
+
+// order[0, n): the rays of the chunk (numbered from index_base) bin after bin; bounds[0..8]: where the octants begin.
+// cursor[256] and *done start at zero; the last workgroup through stores `ready_value` to *ready (if ready is given).
+__global__ __launch_bounds__(COARSE_BLOCK) void coarse_scatter_kernel(const uint8_t *bins, uint32_t n, uint32_t index_base, const uint32_t *hist,
+                                                                      uint32_t *cursor, uint32_t *order, uint32_t *bounds, uint32_t *done,
+                                                                      uint32_t *ready, uint32_t ready_value) {
+	static_assert(COARSE_BLOCK == COARSE_BINS, "one thread per bin");
+	__shared__ uint32_t s_scan[COARSE_BINS], s_count[COARSE_BINS], s_next[COARSE_BINS];
+	const uint32_t t = threadIdx.x;
+	s_scan[t] = hist[t], s_count[t] = 0;
+	__syncthreads();
+	for (uint32_t step = 1; step < COARSE_BINS; step <<= 1) {  // inclusive prefix sums of the 256 counts
+		const uint32_t v = t >= step ? s_scan[t - step] : 0u;
+		__syncthreads();
+		s_scan[t] += v;
+		__syncthreads();
+	}
+	const uint32_t tile = blockIdx.x * COARSE_TILE;
+	for (uint32_t j = 0; j < COARSE_TILE; j += COARSE_BLOCK)
+		if (tile + j + t < n) atomicAdd(&s_count[bins[tile + j + t]], 1u);
+	__syncthreads();
+	// this tile's rays of a bin go behind those of the tiles that asked before it
+	s_next[t] = (t ? s_scan[t - 1] : 0u) + (s_count[t] ? atomicAdd(&cursor[t], s_count[t]) : 0u);
+	__syncthreads();
+	for (uint32_t j = 0; j < COARSE_TILE; j += COARSE_BLOCK) {
+		const uint32_t i = tile + j + t;
+		if (i < n) order[atomicAdd(&s_next[bins[i]], 1u)] = index_base + i;
+	}
+	if (blockIdx.x == 0 && t <= 8) bounds[t] = t == 0 ? 0u : t == 8 ? n : s_scan[t * 32 - 1];
+	// everything this workgroup wrote is visible to the whole GPU before it counts itself as done
+	__threadfence();
+	__syncthreads();
+	if (t == 0 && atomicAdd(done, 1u) == gridDim.x - 1 && ready) {
+		__threadfence();
+		__hip_atomic_store(ready, ready_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+	}
 }
 
 // Announces that a chunk of a batch (its rays and its permutation) is in place: runs on the stream that put it there,

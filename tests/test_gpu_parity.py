@@ -558,11 +558,14 @@ def _page_locked_copy(a):
     return ptr, view
 
 
-@pytest.mark.parametrize("scene,cmds,reorder", [("soup", (), "on"), ("soup", (), "off"), ("skewed", ("sm",), "auto")])
-def test_page_locked_host_batches_in_one_launch(scene, cmds, reorder):
+@pytest.mark.parametrize("scene,cmds,reorder,chunk_order", [("soup", (), "on", "bins"), ("soup", (), "on", "sort"), ("soup", (), "off", "bins"),
+                                                            ("skewed", ("sm",), "auto", "bins"), ("skewed", ("sm",), "auto", "sort")])
+def test_page_locked_host_batches_in_one_launch(scene, cmds, reorder, chunk_order, monkeypatch):
     """Host batches in page-locked memory go through the GPU in one launch that takes up the later chunks of the batch
-    while it runs (each chunk sorted on its own): results are those of the device entry points, ray by ray."""
+    while it runs (each chunk ordered on its own, by octant and length class in two kernels or by the full key with the
+    radix sort): results are those of the device entry points, ray by ray."""
     import torch
+    monkeypatch.setenv("RTGI_HIP_STREAM_COARSE", "1" if chunk_order == "bins" else "0")
     pos, tri, _ = scenes.soup(60000, seed=2, size=0.2) if scene == "soup" else scenes.skewed(60000, seed=6)
     t = tracer.HipBvhTracer(layout="indexed")
     _configure(t, cmds)
