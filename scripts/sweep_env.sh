@@ -1,8 +1,8 @@
 #!/bin/bash
-# usage: scripts/sweep_env.sh OUTFILE "VAR=a VAR2=b" "VAR=c" ...   -- one bench.py run (no CPU leg) per setting
+# usage: scripts/sweep_env.sh OUTFILE "VAR=a VAR2=b" "VAR=c" ...   -- one bench.py run (traversal only) per setting
 out=$1; shift
 : > "$out"
 for setting in "$@"; do
-	line=$(env $setting timeout -k 10 120 python bench.py --no-cpu 2>/dev/null | grep '^{') || exit 1
+	line=$(env $setting timeout -k 10 120 python bench.py --steps 30 --warmup 5 --no-cpu --no-host-buffers --no-extra 2>/dev/null | grep '^{') || exit 1
 	echo "$setting $(echo "$line" | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms'])")" | tee -a "$out"
 done
