@@ -610,7 +610,7 @@ int launch_batches(rtgi_hip_tracer *h, const BatchView *given, uint32_t n_given,
 	if (!h) return RTGI_ERR_INVALID;
 	if (h->device < 0) return fail(h, RTGI_ERR_DEVICE, "host-only handle: traversal needs a GPU");
 	if (!h->built) return fail(h, RTGI_ERR_NOT_BUILT, "no acceleration structure: call build first");
-	if (n_given > (uint32_t)rtgi_dev::MAX_BATCHES) return fail(h, RTGI_ERR_INVALID, "at most 8 batches per launch");
+	if (n_given > (uint32_t)rtgi_dev::MAX_BATCHES) return fail(h, RTGI_ERR_INVALID, "at most 16 batches per launch");
 	BatchView batches[rtgi_dev::MAX_BATCHES];
 	uint32_t n_batches = 0;
 	uint64_t total = 0;
@@ -1644,7 +1644,7 @@ int rtgi_hip_trace_batches_device(rtgi_hip_tracer *h, const rtgi_batch *batches,
 	if (!h) return RTGI_ERR_INVALID;
 	if (n_batches == 0) return RTGI_OK;
 	if (!batches) return fail(h, RTGI_ERR_INVALID, "null batch list");
-	if (n_batches > (uint32_t)rtgi_dev::MAX_BATCHES) return fail(h, RTGI_ERR_INVALID, "at most 8 batches per launch");
+	if (n_batches > (uint32_t)rtgi_dev::MAX_BATCHES) return fail(h, RTGI_ERR_INVALID, "at most 16 batches per launch");
 	BatchView views[rtgi_dev::MAX_BATCHES];
 	for (uint32_t b = 0; b < n_batches; ++b) {
 		if (batches[b].kind != RTGI_BATCH_CLOSEST_HIT && batches[b].kind != RTGI_BATCH_ANY_HIT)
@@ -1696,8 +1696,13 @@ int camera_rays(rtgi_hip_tracer *h, const rtgi_camera *cam, const uint32_t *d_pi
 	a.n = n;
 	hipLaunchKernelGGL(rtgi_dev::camera_rays_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
 	HIP_TRY(h, hipGetLastError());
-	h->camera_rays_at = d_rays;
-	h->camera_rays_n = n;
+	// (camera rays written right behind the last ones - the next sample of the same pixels - make one longer batch in image order)
+	if (h->camera_rays_at && d_rays == static_cast<const rtgi_ray *>(h->camera_rays_at) + h->camera_rays_n && h->camera_rays_n <= 0x7fffffffu - n)
+		h->camera_rays_n += n;
+	else {
+		h->camera_rays_at = d_rays;
+		h->camera_rays_n = n;
+	}
 	return RTGI_OK;
 }
 }  // namespace

@@ -26,6 +26,9 @@ double now_ms() {
 	return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
+constexpr uint32_t MAX_GROUP = 8;            // samples of a part's pixels traced together (two batches each in a path's launches)
+constexpr uint32_t GROUP_RAYS = 2u << 20;    // ... as many as make about this many camera rays
+
 // One GPU's share of the renderer: its tracer handle, its stream and its buffers (all sized for `cap` pixels).
 struct Part {
 	int device = 0;
@@ -165,7 +168,22 @@ int render_part(Part &p, const rtgi_frame &f, int rank, int world) {
 		tile_pixels(f.cam.w, f.cam.h, f.tile ? f.tile : 64u, world, rank, p.pixels);
 	p.n = by_tiles ? (uint32_t)p.pixels.size() : n_full;
 	p.rays = 0;
-	if (int rc = ensure_buffers(p, p.n, n_full)) return rc;
+	// Samples are traced in groups: a launch over fewer rays than the GPU holds at once (256 CUs x 1024 lanes) is all
+	// tail, and a GPU that has an eighth of a frame's tiles gets that few per sample. The buffers hold `group` samples of
+	// this part's pixels one behind the other, the per-ray stages run per sample or over the whole group, and the
+	// traversal launches take the group's rays together. The order in which samples enter the framebuffer is unchanged,
+	// and so is every value in it.
+	uint32_t first, step;
+	sample_share(f.sharding, world, rank, first, step);
+	std::vector<uint32_t> samples;
+	for (uint32_t sample = first; sample < f.sppx; sample += step) samples.push_back(sample);
+	uint32_t group = 1;
+	{
+		const char *e = getenv("RTGI_HIP_FRAME_GROUP");  // most samples per group (1: every sample on its own)
+		const uint32_t most = e ? (uint32_t)std::max(1, std::min(atoi(e), (int)MAX_GROUP)) : MAX_GROUP;
+		if (p.n > 0) group = std::max<uint32_t>(1, std::min<uint32_t>({most, GROUP_RAYS / p.n, (uint32_t)std::max<size_t>(samples.size(), 1)}));
+	}
+	if (int rc = ensure_buffers(p, (size_t)p.n * group, n_full)) return rc;
 	hipStream_t st = p.stream;
 	const uint32_t n = p.n;
 	const uint32_t *d_pixels = nullptr;
@@ -175,64 +193,95 @@ int render_part(Part &p, const rtgi_frame &f, int rank, int world) {
 	}
 	float *fb = by_tiles ? p.d_fb : p.d_full;  // framebuffer::clear
 	PART_HIP(p, hipMemsetAsync(fb, 0, (size_t)std::max<uint32_t>(n, 1) * 16, st));
-	uint32_t first, step;
-	sample_share(f.sharding, world, rank, first, step);
-	for (uint32_t sample = first; sample < f.sppx && n > 0; sample += step) {
-		const float *offsets = nullptr;
-		if (f.jitter) {
+	for (size_t g0 = 0; g0 < samples.size() && n > 0; g0 += group) {
+		const uint32_t S = (uint32_t)std::min<size_t>(group, samples.size() - g0);
+		const uint32_t all = n * S;  // (n * group <= GROUP_RAYS or group == 1: no overflow)
+		for (uint32_t k = 0; k < S; ++k) {  // sample k of the group lives at [k * n, (k + 1) * n) of every buffer
+			const uint32_t sample = samples[g0 + k];
+			const float *offsets = nullptr;
+			if (f.jitter) {
+				float *mine = p.d_offsets + (size_t)k * n * 2;
+				if (d_pixels)
+					PART_RT(p, rtgi_hip_pixel_offsets_pixels_device(p.h, d_pixels, n, sample, f.seed, mine, st));
+				else
+					PART_RT(p, rtgi_hip_pixel_offsets_device(p.h, n, sample, f.seed, mine, st));
+				offsets = mine;
+			}
 			if (d_pixels)
-				PART_RT(p, rtgi_hip_pixel_offsets_pixels_device(p.h, d_pixels, n, sample, f.seed, p.d_offsets, st));
+				PART_RT(p, rtgi_hip_camera_rays_pixels_device(p.h, &f.cam, d_pixels, n, offsets, p.d_rays[0] + (size_t)k * n, st));
 			else
-				PART_RT(p, rtgi_hip_pixel_offsets_device(p.h, n, sample, f.seed, p.d_offsets, st));
-			offsets = p.d_offsets;
+				PART_RT(p, rtgi_hip_camera_rays_device(p.h, &f.cam, offsets, p.d_rays[0] + (size_t)k * n, st));
 		}
-		if (d_pixels)
-			PART_RT(p, rtgi_hip_camera_rays_pixels_device(p.h, &f.cam, d_pixels, n, offsets, p.d_rays[0], st));
-		else
-			PART_RT(p, rtgi_hip_camera_rays_device(p.h, &f.cam, offsets, p.d_rays[0], st));
-		PART_RT(p, rtgi_hip_closest_hit_device(p.h, p.d_rays[0], n, p.d_hits, nullptr, st));
-		p.rays += n;
+		PART_RT(p, rtgi_hip_closest_hit_device(p.h, p.d_rays[0], all, p.d_hits, nullptr, st));
+		p.rays += all;
 		if (f.algo == RTGI_ALGO_PRIMARY) {
-			PART_RT(p, rtgi_hip_shade_primary_device(p.h, p.d_hits, n, p.d_radiance, st));
+			PART_RT(p, rtgi_hip_shade_primary_device(p.h, p.d_hits, all, p.d_radiance, st));
 		} else if (f.algo == RTGI_ALGO_LOCAL) {
-			PART_RT(p, rtgi_hip_shadow_rays_device(p.h, p.d_hits, n, f.light_pos, p.d_shadow, st));
-			PART_RT(p, rtgi_hip_any_hit_device(p.h, p.d_shadow, n, p.d_occluded, nullptr, st));
-			p.rays += n;
-			PART_RT(p, rtgi_hip_shade_local_brdf_device(p.h, p.d_rays[0], p.d_hits, p.d_occluded, n, f.light_pos, f.light_col, p.d_radiance, st));
+			PART_RT(p, rtgi_hip_shadow_rays_device(p.h, p.d_hits, all, f.light_pos, p.d_shadow, st));
+			PART_RT(p, rtgi_hip_any_hit_device(p.h, p.d_shadow, all, p.d_occluded, nullptr, st));
+			p.rays += all;
+			PART_RT(p, rtgi_hip_shade_local_brdf_device(p.h, p.d_rays[0], p.d_hits, p.d_occluded, all, f.light_pos, f.light_col, p.d_radiance, st));
 		} else {
 			// a path per pixel sample: light every vertex, then follow one diffuse bounce, `bounces` times. The shadow
 			// rays of a vertex and the rays of the next segment do not depend on each other: they are traced in ONE
-			// launch (rtgi_hip_trace_batches_device), which ends in one tail instead of two.
-			PART_RT(p, rtgi_hip_path_begin_device(p.h, n, p.d_throughput[0], p.d_slot[0], p.d_radiance, st));
+			// launch (rtgi_hip_trace_batches_device), which ends in one tail instead of two - for all samples of the group.
 			rtgi_hit *hits[2] = {p.d_hits, p.d_hits2};
-			uint32_t m = n;
+			uint32_t m[MAX_GROUP], next[MAX_GROUP];
+			for (uint32_t k = 0; k < S; ++k) {
+				const size_t at = (size_t)k * n;
+				PART_RT(p, rtgi_hip_path_begin_device(p.h, n, p.d_throughput[0] + at * 4, p.d_slot[0] + at, p.d_radiance + at * 4, st));
+				m[k] = n;
+			}
 			int cur = 0, hcur = 0;
 			for (uint32_t depth = 0;; ++depth) {
-				PART_RT(p, rtgi_hip_shadow_rays_device(p.h, hits[hcur], m, f.light_pos, p.d_shadow, st));
-				uint32_t next = 0;
-				if (depth < f.bounces) {
-					PART_RT(p, rtgi_hip_shade_primary_device(p.h, hits[hcur], m, p.d_albedo, st));
-					// (seed: one stream of numbers per sample; keys: the pixel, so that a path does not depend on the sharding)
-					PART_RT(p, rtgi_hip_bounce_rays_keyed_device(p.h, p.d_rays[cur], hits[hcur], m, p.d_slot[cur], d_pixels,
-					                                             f.seed * 0x9E3779B1u + sample, depth + 1, p.d_rays[1 - cur], p.d_parent, p.d_count, st));
-					// the number of rays that go on is needed on the host: the next launches are sized by it
-					PART_HIP(p, hipMemcpyAsync(&next, p.d_count, 4, hipMemcpyDeviceToHost, st));
-					PART_HIP(p, hipStreamSynchronize(st));
+				for (uint32_t k = 0; k < S; ++k) {
+					const size_t at = (size_t)k * n;
+					next[k] = 0;
+					if (m[k] == 0) continue;
+					PART_RT(p, rtgi_hip_shadow_rays_device(p.h, hits[hcur] + at, m[k], f.light_pos, p.d_shadow + at, st));
+					if (depth < f.bounces) {
+						PART_RT(p, rtgi_hip_shade_primary_device(p.h, hits[hcur] + at, m[k], p.d_albedo + at * 4, st));
+						// (seed: one stream of numbers per sample; keys: the pixel, so that a path does not depend on the sharding)
+						PART_RT(p, rtgi_hip_bounce_rays_keyed_device(p.h, p.d_rays[cur] + at, hits[hcur] + at, m[k], p.d_slot[cur] + at, d_pixels,
+						                                             f.seed * 0x9E3779B1u + samples[g0 + k], depth + 1, p.d_rays[1 - cur] + at,
+						                                             p.d_parent + at, p.d_count + k, st));
+					}
 				}
-				const rtgi_batch both[2] = {{p.d_shadow, p.d_occluded, m, RTGI_BATCH_ANY_HIT}, {p.d_rays[1 - cur], hits[1 - hcur], next, RTGI_BATCH_CLOSEST_HIT}};
-				PART_RT(p, rtgi_hip_trace_batches_device(p.h, both, next ? 2 : 1, st));
-				p.rays += (uint64_t)m + next;
-				PART_RT(p, rtgi_hip_shade_local_brdf_device(p.h, p.d_rays[cur], hits[hcur], p.d_occluded, m, f.light_pos, f.light_col, p.d_direct, st));
-				PART_RT(p, rtgi_hip_path_add_device(p.h, p.d_direct, p.d_throughput[cur], p.d_slot[cur], m, p.d_radiance, st));
-				if (next == 0) break;
-				PART_RT(p, rtgi_hip_path_extend_device(p.h, p.d_albedo, p.d_parent, next, p.d_throughput[cur], p.d_slot[cur],
-				                                       p.d_throughput[1 - cur], p.d_slot[1 - cur], st));
+				if (depth < f.bounces) {
+					// the numbers of rays that go on are needed on the host: the next launches are sized by them
+					PART_HIP(p, hipMemcpyAsync(next, p.d_count, S * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+					PART_HIP(p, hipStreamSynchronize(st));
+					for (uint32_t k = 0; k < S; ++k)
+						if (m[k] == 0) next[k] = 0;
+				}
+				rtgi_batch both[2 * MAX_GROUP];
+				uint32_t n_both = 0, more = 0;
+				for (uint32_t k = 0; k < S; ++k) {
+					const size_t at = (size_t)k * n;
+					if (m[k]) both[n_both++] = {p.d_shadow + at, p.d_occluded + at, m[k], RTGI_BATCH_ANY_HIT};
+					if (next[k]) both[n_both++] = {p.d_rays[1 - cur] + at, hits[1 - hcur] + at, next[k], RTGI_BATCH_CLOSEST_HIT};
+					p.rays += (uint64_t)m[k] + next[k];
+					more += next[k] != 0;
+				}
+				if (n_both) PART_RT(p, rtgi_hip_trace_batches_device(p.h, both, n_both, st));
+				for (uint32_t k = 0; k < S; ++k) {
+					const size_t at = (size_t)k * n;
+					if (m[k] == 0) continue;
+					PART_RT(p, rtgi_hip_shade_local_brdf_device(p.h, p.d_rays[cur] + at, hits[hcur] + at, p.d_occluded + at, m[k], f.light_pos, f.light_col,
+					                                            p.d_direct + at * 4, st));
+					PART_RT(p, rtgi_hip_path_add_device(p.h, p.d_direct + at * 4, p.d_throughput[cur] + at * 4, p.d_slot[cur] + at, m[k], p.d_radiance + at * 4, st));
+					if (next[k])
+						PART_RT(p, rtgi_hip_path_extend_device(p.h, p.d_albedo + at * 4, p.d_parent + at, next[k], p.d_throughput[cur] + at * 4, p.d_slot[cur] + at,
+						                                       p.d_throughput[1 - cur] + at * 4, p.d_slot[1 - cur] + at, st));
+					m[k] = next[k];
+				}
+				if (more == 0) break;
 				cur = 1 - cur;
 				hcur = 1 - hcur;
-				m = next;
 			}
 		}
-		PART_RT(p, rtgi_hip_framebuffer_add_device(p.h, fb, p.d_radiance, n, st));
+		for (uint32_t k = 0; k < S; ++k)  // in the order of the samples: the framebuffer keeps a running mean
+			PART_RT(p, rtgi_hip_framebuffer_add_device(p.h, fb, p.d_radiance + (size_t)k * n * 4, n, st));
 	}
 	if (by_tiles) {
 		PART_HIP(p, hipMemsetAsync(p.d_full, 0, (size_t)n_full * 16, st));

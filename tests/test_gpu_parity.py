@@ -430,7 +430,24 @@ def test_several_batches_in_one_launch(scene, cmds, n):
             assert (outs[k].cpu().numpy() == o.any_hit(part)).all(), "batch %d" % k
     t.trace_batches_device([])  # nothing to do
     with pytest.raises(tracer.RtgiHipError):
-        t.trace_batches_device(batches * 3)  # more than 8
+        t.trace_batches_device(batches * 5)  # more than 16
+    # sixteen batches, the most a launch takes (the frame level traces the shadow and bounce rays of eight samples together)
+    edges = [n * k // 16 for k in range(17)]
+    many, many_out = [], []
+    for k in range(16):
+        part = d_all[edges[k]:edges[k + 1]].contiguous()
+        m = edges[k + 1] - edges[k]
+        d_out = torch.empty((m, 4), dtype=torch.float32, device="cuda") if k % 2 == 0 else torch.full((m,), 7, dtype=torch.uint8, device="cuda")
+        many.append((part, d_out, "closest" if k % 2 == 0 else "any"))
+        many_out.append(d_out)
+    t.trace_batches_device(many)
+    torch.cuda.synchronize()
+    want_hits, want_any = o.closest_hit(rays), o.any_hit(rays)
+    for k in range(16):
+        if k % 2 == 0:
+            assert_hits_equal(many_out[k].cpu().numpy().view(tracer.HIT_DTYPE).reshape(-1), want_hits[edges[k]:edges[k + 1]], "batch %d of 16" % k)
+        else:
+            assert (many_out[k].cpu().numpy() == want_any[edges[k]:edges[k + 1]]).all(), "batch %d of 16" % k
 
 
 def test_launches_on_different_streams_do_not_overlap_on_the_scratch():
