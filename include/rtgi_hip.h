@@ -191,7 +191,7 @@ int rtgi_hip_closest_hit_device_noalloc(rtgi_hip_tracer *h, const rtgi_ray *d_ra
                                         void *stream);
 
 /* Several batches in one launch (no counterpart in the reference, whose batch adapter takes one buffer at a
- * time, libgi/wavefront-rt.h:67-80): up to 16 batches of rays on the GPU, each either a closest_hit batch (d_out:
+ * time, libgi/wavefront-rt.h:67-80): up to 32 batches of rays on the GPU, each either a closest_hit batch (d_out:
  * rtgi_hit per ray) or an any_hit batch (d_out: one byte per ray). Results are those of the single calls; what is
  * gained is that the batches share one ray supply, so the lanes that the end of one batch leaves idle work on the
  * others (e.g. the shadow rays and the bounce rays of one sample). Empty batches are allowed. */

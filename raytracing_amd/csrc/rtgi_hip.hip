@@ -610,7 +610,7 @@ int launch_batches(rtgi_hip_tracer *h, const BatchView *given, uint32_t n_given,
 	if (!h) return RTGI_ERR_INVALID;
 	if (h->device < 0) return fail(h, RTGI_ERR_DEVICE, "host-only handle: traversal needs a GPU");
 	if (!h->built) return fail(h, RTGI_ERR_NOT_BUILT, "no acceleration structure: call build first");
-	if (n_given > (uint32_t)rtgi_dev::MAX_BATCHES) return fail(h, RTGI_ERR_INVALID, "at most 16 batches per launch");
+	if (n_given > (uint32_t)rtgi_dev::MAX_BATCHES) return fail(h, RTGI_ERR_INVALID, "at most 32 batches per launch");
 	BatchView batches[rtgi_dev::MAX_BATCHES];
 	uint32_t n_batches = 0;
 	uint64_t total = 0;
@@ -1644,7 +1644,7 @@ int rtgi_hip_trace_batches_device(rtgi_hip_tracer *h, const rtgi_batch *batches,
 	if (!h) return RTGI_ERR_INVALID;
 	if (n_batches == 0) return RTGI_OK;
 	if (!batches) return fail(h, RTGI_ERR_INVALID, "null batch list");
-	if (n_batches > (uint32_t)rtgi_dev::MAX_BATCHES) return fail(h, RTGI_ERR_INVALID, "at most 16 batches per launch");
+	if (n_batches > (uint32_t)rtgi_dev::MAX_BATCHES) return fail(h, RTGI_ERR_INVALID, "at most 32 batches per launch");
 	BatchView views[rtgi_dev::MAX_BATCHES];
 	for (uint32_t b = 0; b < n_batches; ++b) {
 		if (batches[b].kind != RTGI_BATCH_CLOSEST_HIT && batches[b].kind != RTGI_BATCH_ANY_HIT)

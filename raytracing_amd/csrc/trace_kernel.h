@@ -50,7 +50,7 @@ constexpr int WAVES_PER_SIMD = RTGI_WAVES_PER_SIMD;  // resident waves per SIMD 
 constexpr int MAX_STACK_LDS = 24;  // at most this many pending nodes per lane in LDS (beyond the one in a register)
 constexpr int DEEP_STACK_LDS = 20; // trees deeper than MAX_STACK_LDS: this many in LDS, the rest in the global spill area
 constexpr int COUNTER_STRIDE = 32;
-constexpr int MAX_BATCHES = 16;
+constexpr int MAX_BATCHES = 32;
 constexpr int MAX_CHUNKS = 6;
 constexpr int32_t IDLE = INT32_MIN;  // lane has no ray; leaf references are ~slot with slot < 2^30
 

@@ -430,11 +430,11 @@ def test_several_batches_in_one_launch(scene, cmds, n):
             assert (outs[k].cpu().numpy() == o.any_hit(part)).all(), "batch %d" % k
     t.trace_batches_device([])  # nothing to do
     with pytest.raises(tracer.RtgiHipError):
-        t.trace_batches_device(batches * 5)  # more than 16
-    # sixteen batches, the most a launch takes (the frame level traces the shadow and bounce rays of eight samples together)
-    edges = [n * k // 16 for k in range(17)]
+        t.trace_batches_device(batches * 9)  # more than 32
+    # thirty-two batches, the most a launch takes (the frame level traces the shadow and bounce rays of sixteen samples together)
+    edges = [n * k // 32 for k in range(33)]
     many, many_out = [], []
-    for k in range(16):
+    for k in range(32):
         part = d_all[edges[k]:edges[k + 1]].contiguous()
         m = edges[k + 1] - edges[k]
         d_out = torch.empty((m, 4), dtype=torch.float32, device="cuda") if k % 2 == 0 else torch.full((m,), 7, dtype=torch.uint8, device="cuda")
@@ -443,11 +443,11 @@ def test_several_batches_in_one_launch(scene, cmds, n):
     t.trace_batches_device(many)
     torch.cuda.synchronize()
     want_hits, want_any = o.closest_hit(rays), o.any_hit(rays)
-    for k in range(16):
+    for k in range(32):
         if k % 2 == 0:
-            assert_hits_equal(many_out[k].cpu().numpy().view(tracer.HIT_DTYPE).reshape(-1), want_hits[edges[k]:edges[k + 1]], "batch %d of 16" % k)
+            assert_hits_equal(many_out[k].cpu().numpy().view(tracer.HIT_DTYPE).reshape(-1), want_hits[edges[k]:edges[k + 1]], "batch %d of 32" % k)
         else:
-            assert (many_out[k].cpu().numpy() == want_any[edges[k]:edges[k + 1]]).all(), "batch %d of 16" % k
+            assert (many_out[k].cpu().numpy() == want_any[edges[k]:edges[k + 1]]).all(), "batch %d of 32" % k
 
 
 def test_launches_on_different_streams_do_not_overlap_on_the_scratch():
