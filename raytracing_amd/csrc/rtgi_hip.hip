@@ -198,6 +198,7 @@ struct rtgi_hip_tracer {
 	std::vector<rtgi_ray> probe_rays;
 	uint32_t node_bytes = 0, tri_bytes = 0;
 	int refill_min = 24, leaf_min = 12, drain_leaf_min = 4;
+	bool leaf_min_given = false, drain_leaf_min_given = false;  // RTGI_HIP_LEAF_MIN / _DRAIN_LEAF_MIN are set: upload does not choose them by the tree's leaves
 	bool top_in_lds = true;
 	uint32_t blocks_per_cu = 1;
 	// division of a workgroup's LDS (set at upload from the tree's depth and size, see trace_kernel.h)
@@ -310,6 +311,8 @@ void read_tunables(rtgi_hip_tracer *h) {
 	h->blocks_per_cu = (uint32_t)number("RTGI_HIP_BLOCKS_PER_CU", 1, 16, (int)h->blocks_per_cu);
 	h->refill_min = number("RTGI_HIP_REFILL_MIN", 1, 64, h->refill_min);
 	h->leaf_min = number("RTGI_HIP_LEAF_MIN", 1, 64, h->leaf_min);
+	h->leaf_min_given = getenv("RTGI_HIP_LEAF_MIN") != nullptr;
+	h->drain_leaf_min_given = getenv("RTGI_HIP_DRAIN_LEAF_MIN") != nullptr;
 	h->drain_leaf_min = number("RTGI_HIP_DRAIN_LEAF_MIN", 1, 64, h->drain_leaf_min);
 	h->n_segments = number("RTGI_HIP_SEGMENTS", 1, 8, 8) == 1 ? 1u : 8u;
 	h->top_in_lds = number("RTGI_HIP_TOP_IN_LDS", 0, 1, 1) != 0;
@@ -400,6 +403,16 @@ int upload_flat(rtgi_hip_tracer *h, const rtgi::FlatTree &flat, const rtgi::Scen
 		h->scene_inv_extent[k] = hi[k] > lo[k] ? 1.0f / (hi[k] - lo[k]) : 0.0f;
 	}
 	h->root_ref = flat.root_ref;
+	// How many lanes wait at leaves before the triangle code runs for them: a leaf's triangles are tested one after the other,
+	// each a fetch and a hundred instructions for the lanes that wait, so trees with larger leaves gather more lanes first.
+	// Measured on the 2^20-triangle soup (`bvh triangles multiple` 1 / 2 / 4 / 8: 4.6 / 21 / 53 / 128 triangle tests per ray):
+	// best at 12 / 20-24 / 24-32 / 32 waiting lanes, +5 / +12 / +29 % over 12 for the last three.
+	if (!h->leaf_min_given) {
+		const double per_leaf = (double)flat.n_slots / (double)(flat.n_inner + 1u);
+		h->leaf_min = (int)std::min(32.0, std::max(12.0, 12.0 + 10.0 * std::log2(std::max(per_leaf, 1.0))));
+	}
+	// (once the supply is dry a third of that: 4 for one triangle per leaf; four-triangle leaves 8-12: another 3-5 %)
+	if (!h->drain_leaf_min_given) h->drain_leaf_min = std::max(4, h->leaf_min / 3);
 	// node record: l.min.x r.min.x l.min.y r.min.y l.min.z r.min.z | the six max planes in the same order | links
 	h->boxes_ordered = !getenv("RTGI_HIP_NO_OCTANT_WAVES");
 	for (size_t i = 0; h->boxes_ordered && i + 16 <= flat.nodes.size(); i += 16)
