@@ -194,6 +194,7 @@ struct rtgi_hip_tracer {
 	// "auto": sorting pays where incoherent rays are expensive. probe_pops is the mean number of inner nodes a
 	// closest_hit ray pops when it starts on a random triangle in a random direction, measured at upload.
 	float probe_pops = 0.0f;
+	float probe_tris = 0.0f;  // ... and the mean number of triangles it tests; a triangle test counts as two node visits
 	float reorder_min_pops = 120.0f;
 	std::vector<rtgi_ray> probe_rays;
 	uint32_t node_bytes = 0, tri_bytes = 0;
@@ -426,6 +427,7 @@ int upload_flat(rtgi_hip_tracer *h, const rtgi::FlatTree &flat, const rtgi::Scen
 	// probe rays for the reorder policy: from random points of random triangles into random directions
 	h->probe_rays.clear();
 	h->probe_pops = 0.0f;
+	h->probe_tris = 0.0f;
 	if (!h->refill_min_given) h->refill_min = 40;  // (scenes too small for probe rays: short rays; larger ones: see probe_scene)
 	if (flat.n_slots >= 4096) {
 		uint64_t state = 0x9E3779B97F4A7C15ull;
@@ -650,7 +652,7 @@ int launch_batches(rtgi_hip_tracer *h, const BatchView *given, uint32_t n_given,
 		if (int rc = turn.begin()) return rc;
 	// (auto: not for a batch that this handle itself filled with camera rays, which are in image order)
 	const bool camera_batch = n_batches == 1 && batches[0].rays == h->camera_rays_at && n == h->camera_rays_n;
-	bool sort = (h->reorder == 1 || (h->reorder == 2 && h->probe_pops > h->reorder_min_pops && !camera_batch)) && n >= h->reorder_min &&
+	bool sort = (h->reorder == 1 || (h->reorder == 2 && h->probe_pops + 2.0f * h->probe_tris > h->reorder_min_pops && !camera_batch)) && n >= h->reorder_min &&
 	            n < (1u << 31);  // (the sort counts in int)
 	Scratch sc;
 	if (fixed) {
@@ -1115,7 +1117,7 @@ int trace_host(rtgi_hip_tracer *h, const rtgi_ray *rays, uint32_t n, void *out) 
 	// (the kernel stores hit records as 16-byte words: a destination that is not aligned to them gets its results by a copy)
 	const bool out_aligned = ANY || (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
 	if (h->host_streamed && rays_locked && out_locked && out_aligned && n >= h->stream_min && n < (1u << 31)) {
-		const bool sort = (h->reorder == 1 || (h->reorder == 2 && h->probe_pops > h->reorder_min_pops)) && n >= 4 * h->reorder_min;
+		const bool sort = (h->reorder == 1 || (h->reorder == 2 && h->probe_pops + 2.0f * h->probe_tris > h->reorder_min_pops)) && n >= 4 * h->reorder_min;
 		HIP_TRY(h, hipStreamSynchronize(nullptr));  // (work that earlier calls left on the default stream comes first)
 		bool fell_back = true;
 		rc = trace_host_streamed<ANY>(h, rays, n, out, sort, &fell_back);
@@ -1237,9 +1239,10 @@ int probe_scene(rtgi_hip_tracer *h) {
 	h->probe_rays.shrink_to_fit();
 	if (rc) return rc;
 	HIP_TRY(h, e);
-	double pops = 0.0;
-	for (uint32_t i = 0; i < n; ++i) pops += counts[2 * (size_t)i];
+	double pops = 0.0, tris = 0.0;
+	for (uint32_t i = 0; i < n; ++i) pops += counts[2 * (size_t)i], tris += counts[2 * (size_t)i + 1];
 	h->probe_pops = (float)(pops / n);
+	h->probe_tris = (float)(tris / n);
 	// Idle lanes before a wave draws new rays: a refill is an atomic, a fetch of the order and a fetch of the rays, one after the
 	// other. Where rays are short (few nodes each) refills come often and larger ones pay: 40 idle lanes against 24 make camera
 	// and shadow rays of the terrain scene 8 / 13 % faster, of the sponza-class scene 3 / 0 %, of the stadium scene 5 / 5 %, bounce
