@@ -245,6 +245,28 @@ struct rtgi_hip_tracer {
 
 namespace {
 
+// The radix sort of (24-bit key, ray number) pairs: rocPRIM's Onesweep. For batches of up to a few million pairs the
+// library's own choice of tile (and, below 2^20 pairs, of a merge sort) leaves most of the GPU idle; workgroups of 1024 x 4
+// pairs and a histogram kernel of 512 x 16 sort the benchmark batch (1.45 M pairs) in 87 instead of 108 microseconds and
+// half a million pairs in 58 instead of 120; from about 3 M pairs on the library's choice is the faster one
+// (scripts/ubench/sort_configs.hip). The size query (temp == nullptr) and the sort itself choose alike.
+// beside_launch: the sort runs while a traversal launch holds half of every CU's wave slots and registers; the 1024-thread
+// workgroups would never be scheduled there, the library's own configuration is.
+hipError_t sort_pairs(void *temp, size_t &temp_bytes, hipcub::DoubleBuffer<uint32_t> &keys, hipcub::DoubleBuffer<uint32_t> &index, uint32_t n,
+                      hipStream_t stream, bool beside_launch = false) {
+	if (n >= 3000000u || beside_launch) return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, index, (int)n, 0, rtgi_dev::KEY_BITS, stream);
+	using small_batches = rocprim::radix_sort_config<
+	    rocprim::default_config, rocprim::default_config,
+	    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<512, 16>, rocprim::kernel_config<1024, 4>, 8, rocprim::block_radix_rank_algorithm::match>, 1024>;
+	rocprim::double_buffer<uint32_t> k(keys.Current(), keys.Alternate()), v(index.Current(), index.Alternate());
+	const hipError_t e = rocprim::radix_sort_pairs<small_batches>(temp, temp_bytes, k, v, n, 0u, (unsigned)rtgi_dev::KEY_BITS, stream);
+	if (temp && e == hipSuccess) {  // (which array of each pair holds the result)
+		if (k.current() != keys.Current()) keys.selector ^= 1;
+		if (v.current() != index.Current()) index.selector ^= 1;
+	}
+	return e;
+}
+
 int fail(rtgi_hip_tracer *h, int code, const std::string &msg) {
 	if (h) h->error = msg;
 	return code;
@@ -517,7 +539,7 @@ int handle_scratch(rtgi_hip_tracer *h, uint32_t n, bool sort, Scratch &sc) {
 		// the sort's scratch size depends on the item count (the library picks its algorithm by size): ask for this n
 		size_t temp = 0;
 		hipcub::DoubleBuffer<uint32_t> keys(h->d_sort, h->d_sort + h->sort_cap), index(h->d_sort + 2 * h->sort_cap, h->d_sort + 3 * h->sort_cap);
-		HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(nullptr, temp, keys, index, (int)n, 0, rtgi_dev::KEY_BITS, nullptr));
+		HIP_TRY(h, sort_pairs(nullptr, temp, keys, index, (uint32_t)(n), nullptr));
 		if (temp > h->sort_temp_bytes) {
 			if (h->d_sort_temp) (void)hipFree(h->d_sort_temp);
 			h->d_sort_temp = nullptr;
@@ -565,7 +587,7 @@ int sort_rays(rtgi_hip_tracer *h, const BatchView *batches, uint32_t n_batches, 
 	// permutations for batches of up to a few 100 k items with rocPRIM of ROCm 7.2.) The two array pairs are the
 	// sort's double buffers: which of each pair holds the result is known on the host when the call returns.
 	size_t temp_size = sc.sort_temp_bytes;
-	HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(sc.sort_temp, temp_size, keys, index, (int)n, 0, rtgi_dev::KEY_BITS, stream));
+	HIP_TRY(h, sort_pairs(sc.sort_temp, temp_size, keys, index, (uint32_t)(n), stream));
 	HIP_TRY(h, debug_sync(h, "radix sort", stream));
 	hipLaunchKernelGGL(rtgi_dev::segment_bounds_kernel, dim3(1), dim3(512), 0, stream, keys.Current(), n,
 	                   sc.counter + 8 * rtgi_dev::COUNTER_STRIDE);
@@ -661,7 +683,7 @@ int launch_batches(rtgi_hip_tracer *h, const BatchView *given, uint32_t n_given,
 			size_t temp = 0;
 			hipcub::DoubleBuffer<uint32_t> keys(sc.sort, sc.sort + sc.sort_cap), index(sc.sort + 2 * sc.sort_cap, sc.sort + 3 * sc.sort_cap);
 			sort = n <= sc.sort_cap &&
-			       hipcub::DeviceRadixSort::SortPairs(nullptr, temp, keys, index, (int)n, 0, rtgi_dev::KEY_BITS, stream) == hipSuccess &&
+			       sort_pairs(nullptr, temp, keys, index, (uint32_t)(n), stream) == hipSuccess &&
 			       temp <= sc.sort_temp_bytes;
 		}
 	} else if (int rc = handle_scratch(h, n, sort, sc))
@@ -941,7 +963,7 @@ int trace_host_streamed(rtgi_hip_tracer *h, const rtgi_ray *rays, uint32_t n, vo
 		for (uint32_t c = 0; c < n_chunks; ++c) {
 			size_t temp = 0;
 			hipcub::DoubleBuffer<uint32_t> keys(sc.sort, sc.sort + cap), index(sc.sort + 2 * cap, sc.sort + 3 * cap);
-			HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(nullptr, temp, keys, index, (int)(ends[c] - (c ? ends[c - 1] : 0)), 0, KEY_BITS, nullptr));
+			HIP_TRY(h, sort_pairs(nullptr, temp, keys, index, (uint32_t)((ends[c] - (c ? ends[c - 1] : 0))), nullptr, true));
 			need = std::max(need, temp);
 		}
 		if (need > h->sort_temp_bytes) {
@@ -1007,7 +1029,7 @@ int trace_host_streamed(rtgi_hip_tracer *h, const rtgi_ray *rays, uint32_t n, vo
 			k.index_base = begin;
 			hipLaunchKernelGGL(ray_keys_kernel, dim3((count + 255) / 256), dim3(256), 0, p.aux, k);
 			size_t temp_size = sc.sort_temp_bytes;
-			HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(sc.sort_temp, temp_size, keys, index, (int)count, 0, KEY_BITS, p.aux));
+			HIP_TRY(h, sort_pairs(sc.sort_temp, temp_size, keys, index, (uint32_t)(count), p.aux, true));
 			uint32_t *bounds = h->d_stream_ctl + CTL_BOUNDS + c * 16;
 			hipLaunchKernelGGL(segment_bounds_kernel, dim3(1), dim3(512), 0, p.aux, keys.Current(), count, bounds);
 			a.chunk_order[c] = index.Current() - begin;  // (indexed by the position in the whole batch)

@@ -34,6 +34,16 @@ def test_noalloc_two_calls_sorted_batches():
     second = _both(t, _mixed_rays(pos, 70001, seed=22))   # smaller: the array still holds the first call's contents
     third = _both(t, _mixed_rays(pos, 1000, seed=23))     # below the sort threshold
     assert (first["t"] != tracer.FLT_MAX).any() and (second["t"] != tracer.FLT_MAX).any() and len(third) == 1000
+    # the largest batch the entry point takes is still sorted inside the fixed array (the sort's own scratch fits)
+    import torch
+    before = t.launch_stats()
+    n = 1 << 21
+    d_rays = torch.from_numpy(_mixed_rays(pos, n, seed=24)).cuda()
+    d_hits = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+    t.closest_hit_device_noalloc(d_rays, d_hits)
+    torch.cuda.synchronize()
+    after = t.launch_stats()
+    assert after["launches"] == before["launches"] + 1 and after["sorted"] == before["sorted"] + 1
     t.close()
 
 
