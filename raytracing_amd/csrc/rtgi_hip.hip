@@ -589,8 +589,8 @@ int sort_rays(rtgi_hip_tracer *h, const BatchView *batches, uint32_t n_batches, 
 	size_t temp_size = sc.sort_temp_bytes;
 	HIP_TRY(h, sort_pairs(sc.sort_temp, temp_size, keys, index, (uint32_t)(n), stream));
 	HIP_TRY(h, debug_sync(h, "radix sort", stream));
-	hipLaunchKernelGGL(rtgi_dev::segment_bounds_kernel, dim3(1), dim3(512), 0, stream, keys.Current(), n,
-	                   sc.counter + 8 * rtgi_dev::COUNTER_STRIDE);
+	hipLaunchKernelGGL(rtgi_dev::segment_bounds_kernel, dim3(1), dim3(512), 0, stream, (const uint32_t *)keys.Current(), n,
+	                   sc.counter + 8 * rtgi_dev::COUNTER_STRIDE, sc.counter);  // (also zeroes the ray counters)
 	HIP_TRY(h, debug_sync(h, "segment_bounds_kernel", stream));
 	*order = index.Current();
 	return RTGI_OK;
@@ -767,7 +767,7 @@ int launch_batches(rtgi_hip_tracer *h, const BatchView *given, uint32_t n_given,
 		a.seg_bounds = sc.counter + 8 * rtgi_dev::COUNTER_STRIDE;  // one part per direction octant
 		a.n_segments = 8;
 	}
-	HIP_TRY(h, hipMemsetAsync(sc.counter, 0, 8 * rtgi_dev::COUNTER_STRIDE * sizeof(uint32_t), stream));
+	if (!sort) HIP_TRY(h, hipMemsetAsync(sc.counter, 0, 8 * rtgi_dev::COUNTER_STRIDE * sizeof(uint32_t), stream));
 	hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 	if (!fixed && h->profiling && h->events_used < 4096) {
 		if (h->events_used == h->events.size()) {
@@ -1031,7 +1031,7 @@ int trace_host_streamed(rtgi_hip_tracer *h, const rtgi_ray *rays, uint32_t n, vo
 			size_t temp_size = sc.sort_temp_bytes;
 			HIP_TRY(h, sort_pairs(sc.sort_temp, temp_size, keys, index, (uint32_t)(count), p.aux, true));
 			uint32_t *bounds = h->d_stream_ctl + CTL_BOUNDS + c * 16;
-			hipLaunchKernelGGL(segment_bounds_kernel, dim3(1), dim3(512), 0, p.aux, keys.Current(), count, bounds);
+			hipLaunchKernelGGL(segment_bounds_kernel, dim3(1), dim3(512), 0, p.aux, (const uint32_t *)keys.Current(), count, bounds, (uint32_t *)nullptr);
 			a.chunk_order[c] = index.Current() - begin;  // (indexed by the position in the whole batch)
 			a.chunk_bounds[c] = bounds;
 		}

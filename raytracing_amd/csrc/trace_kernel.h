@@ -708,7 +708,10 @@ __global__ void await_word_kernel(const uint32_t *word, uint32_t *seen, uint32_t
 
 // Positions in the sorted key array where the direction octant changes: the 8 parts of the batch that the 8
 // XCDs start on (bounds[8] = n). One wave per boundary; every step cuts the candidate range into 64 parts.
-__global__ __launch_bounds__(512) void segment_bounds_kernel(const uint32_t *sorted_keys, uint32_t n, uint32_t *bounds) {
+// It also sets the launch's ray counters (the COUNTER_STRIDE * 8 words before `bounds`) to zero, if asked to: one small
+// operation less on the stream before every sorted launch.
+__global__ __launch_bounds__(512) void segment_bounds_kernel(const uint32_t *sorted_keys, uint32_t n, uint32_t *bounds, uint32_t *counters) {
+	if (counters && threadIdx.x < 8 * COUNTER_STRIDE) counters[threadIdx.x] = 0;
 	const uint32_t s = threadIdx.x >> 6, lane = threadIdx.x & 63u;
 	const uint32_t want = s << 21;
 	uint32_t lo = 0, hi = n;  // the first position whose key is >= want lies in [lo, hi]
