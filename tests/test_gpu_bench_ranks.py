@@ -42,3 +42,12 @@ def test_one_rank_over_rccl():
     line = _launch(1, ["--cpu-seconds", "2", "--no-host-buffers"])
     assert line["n_gpus"] == 1 and line["value"] > 0
     assert line["cpu_baseline"]["hits_identical_to_gpu"] is True
+
+
+def test_one_rank_frame_over_rccl():
+    # whole frames through the C++ frame level, launched by torch.distributed.run: the RCCL id travels over the process
+    # group, the framebuffer through ncclAllReduce (a world of one rank here), samples are traced in groups
+    line = _launch(1, ["--frame", "--sppx", "5"])
+    assert line["n_gpus"] == 1 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["framebuffer_exchange"]["used_rccl"] == 1
+    assert line["config"]["sppx"] == 5
