@@ -119,7 +119,8 @@ uint32_t rtgi_hip_root(const rtgi_hip_tracer *h);
 uint32_t rtgi_hip_depth(const rtgi_hip_tracer *h);     /* deepest leaf, root = 0 */
 /* What "hip reorder auto" decides by (no counterpart in the reference): the mean number of inner nodes a
  * closest_hit ray pops when it starts on a random triangle in a random direction, measured on the GPU at
- * build / upload with 32768 seeded rays. Batches are sorted before tracing where this exceeds 120.
+ * build / upload with 32768 seeded rays. Batches are sorted before tracing where this plus twice the triangles such a
+ * ray tests exceeds 120; where it is below 100 waves draw new rays in larger portions (short rays, frequent refills).
  * 0 for host-only handles and scenes of fewer than 4096 leaf slots. */
 float rtgi_hip_incoherent_ray_cost(const rtgi_hip_tracer *h);
 int rtgi_hip_get_nodes(const rtgi_hip_tracer *h, rtgi_node56 *out);
