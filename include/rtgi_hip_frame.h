@@ -16,7 +16,7 @@
  * all-reduce over xGMI of sums and counts (framebuffer::add keeps a running mean with its count in .w,
  * libgi/framebuffer.cpp:10-18; means cannot be added). With tiles a pixel has samples on one GPU only, and the
  * combined frame is bit-identical to the frame one GPU renders. A GPU traces several samples of its pixels per launch
- * (as many as make about 8 Mi camera rays, at most 16: a launch over the few pixels of an eighth of a frame would be
+ * (as many as make about 8 Mi camera rays, at most 31: a launch over the few pixels of an eighth of a frame would be
  * over before the GPU is busy); samples still enter the framebuffer in their order, the frame does not change.
  *
  * Conventions as in rtgi_hip.h: 0 or a negative RTGI_ERR_* code, never throws, never aborts; one renderer is used

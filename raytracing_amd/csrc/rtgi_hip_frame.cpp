@@ -26,7 +26,8 @@ double now_ms() {
 	return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
-constexpr uint32_t MAX_GROUP = 16;           // samples of a part's pixels traced together (two batches each in a path's launches)
+constexpr uint32_t MAX_GROUP = 31;           // samples of a part's pixels traced together (a path's launches: one batch of all their shadow
+                                             // rays and one batch of bounce rays per sample, at most 32 batches)
 constexpr uint32_t GROUP_RAYS = 8u << 20;    // ... as many as make about this many camera rays (2 Mi: 1133, 4 Mi: 1221, 8 Mi: 1260,
                                              // 16 Mi: 1273 Mrays/s over a path-traced 1080p frame)
 
@@ -185,6 +186,9 @@ int render_part(Part &p, const rtgi_frame &f, int rank, int world) {
 		const char *e2 = getenv("RTGI_HIP_FRAME_GROUP_RAYS");  // camera rays per group to aim for
 		const uint32_t aim = e2 ? (uint32_t)std::max(1, std::min(atoi(e2), 1 << 28)) : GROUP_RAYS;
 		if (p.n > 0) group = std::max<uint32_t>(1, std::min<uint32_t>({most, aim / p.n, (uint32_t)std::max<size_t>(samples.size(), 1)}));
+		// (groups of equal size rather than full ones and a small rest)
+		const uint32_t n_groups = ((uint32_t)samples.size() + group - 1) / group;
+		if (n_groups > 0) group = ((uint32_t)samples.size() + n_groups - 1) / n_groups;
 	}
 	if (int rc = ensure_buffers(p, (size_t)p.n * group, n_full)) return rc;
 	hipStream_t st = p.stream;
@@ -229,7 +233,7 @@ int render_part(Part &p, const rtgi_frame &f, int rank, int world) {
 			// rays of a vertex and the rays of the next segment do not depend on each other: they are traced in ONE
 			// launch (rtgi_hip_trace_batches_device), which ends in one tail instead of two - for all samples of the group.
 			rtgi_hit *hits[2] = {p.d_hits, p.d_hits2};
-			uint32_t m[MAX_GROUP], next[MAX_GROUP];
+			uint32_t m[MAX_GROUP], next[MAX_GROUP], at_shadow[MAX_GROUP];  // at_shadow: where a sample's shadow rays begin in the group's
 			for (uint32_t k = 0; k < S; ++k) {
 				const size_t at = (size_t)k * n;
 				PART_RT(p, rtgi_hip_path_begin_device(p.h, n, p.d_throughput[0] + at * 4, p.d_slot[0] + at, p.d_radiance + at * 4, st));
@@ -237,11 +241,14 @@ int render_part(Part &p, const rtgi_frame &f, int rank, int world) {
 			}
 			int cur = 0, hcur = 0;
 			for (uint32_t depth = 0;; ++depth) {
+				uint32_t n_shadow = 0;  // the shadow rays of the group's samples lie one behind the other: one any_hit batch
 				for (uint32_t k = 0; k < S; ++k) {
 					const size_t at = (size_t)k * n;
 					next[k] = 0;
+					at_shadow[k] = n_shadow;
 					if (m[k] == 0) continue;
-					PART_RT(p, rtgi_hip_shadow_rays_device(p.h, hits[hcur] + at, m[k], f.light_pos, p.d_shadow + at, st));
+					PART_RT(p, rtgi_hip_shadow_rays_device(p.h, hits[hcur] + at, m[k], f.light_pos, p.d_shadow + at_shadow[k], st));
+					n_shadow += m[k];
 					if (depth < f.bounces) {
 						PART_RT(p, rtgi_hip_shade_primary_device(p.h, hits[hcur] + at, m[k], p.d_albedo + at * 4, st));
 						// (seed: one stream of numbers per sample; keys: the pixel, so that a path does not depend on the sharding)
@@ -257,11 +264,11 @@ int render_part(Part &p, const rtgi_frame &f, int rank, int world) {
 					for (uint32_t k = 0; k < S; ++k)
 						if (m[k] == 0) next[k] = 0;
 				}
-				rtgi_batch both[2 * MAX_GROUP];
+				rtgi_batch both[1 + MAX_GROUP];
 				uint32_t n_both = 0, more = 0;
+				if (n_shadow) both[n_both++] = {p.d_shadow, p.d_occluded, n_shadow, RTGI_BATCH_ANY_HIT};
 				for (uint32_t k = 0; k < S; ++k) {
 					const size_t at = (size_t)k * n;
-					if (m[k]) both[n_both++] = {p.d_shadow + at, p.d_occluded + at, m[k], RTGI_BATCH_ANY_HIT};
 					if (next[k]) both[n_both++] = {p.d_rays[1 - cur] + at, hits[1 - hcur] + at, next[k], RTGI_BATCH_CLOSEST_HIT};
 					p.rays += (uint64_t)m[k] + next[k];
 					more += next[k] != 0;
@@ -270,7 +277,7 @@ int render_part(Part &p, const rtgi_frame &f, int rank, int world) {
 				for (uint32_t k = 0; k < S; ++k) {
 					const size_t at = (size_t)k * n;
 					if (m[k] == 0) continue;
-					PART_RT(p, rtgi_hip_shade_local_brdf_device(p.h, p.d_rays[cur] + at, hits[hcur] + at, p.d_occluded + at, m[k], f.light_pos, f.light_col,
+					PART_RT(p, rtgi_hip_shade_local_brdf_device(p.h, p.d_rays[cur] + at, hits[hcur] + at, p.d_occluded + at_shadow[k], m[k], f.light_pos, f.light_col,
 					                                            p.d_direct + at * 4, st));
 					PART_RT(p, rtgi_hip_path_add_device(p.h, p.d_direct + at * 4, p.d_throughput[cur] + at * 4, p.d_slot[cur] + at, m[k], p.d_radiance + at * 4, st));
 					if (next[k])

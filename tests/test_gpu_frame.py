@@ -121,20 +121,20 @@ def test_tiles_over_several_handles_are_bit_identical(algo, bounces):
 @pytest.mark.parametrize("algo,bounces,spp", [("primary", 0, 5), ("local", 0, 11), ("path", 3, 11)])
 def test_samples_traced_in_groups_give_the_frame_of_samples_traced_one_by_one(algo, bounces, spp, monkeypatch):
     # a part with few pixels traces several samples per launch (a launch over fewer rays than the GPU holds is all tail):
-    # groups of up to 16 samples, here of 1, 3, 8 (one full group and a rest of three) and 11; the framebuffer must not notice
+    # groups of up to 31 samples, here of at most 1, 3, 8 (balanced: 6 + 5) and all 11; the framebuffer must not notice
     w, h = 190, 100
     s = _cornell()
     kw = dict(fovy=40.0, w=w, h=h, sppx=spp, algo=algo, bounces=bounces, light_pos=CORNELL_LIGHT, light_col=(1.0, 1.0, 1.0), seed=9, **CORNELL_CAM)
     frames = {}
-    for most in ("1", "3", "8", "16"):
+    for most in ("1", "3", "8", "31"):
         monkeypatch.setenv("RTGI_HIP_FRAME_GROUP", most)
         frames[most] = _renderer(s).render(**kw)
-    for most in ("3", "8", "16"):
+    for most in ("3", "8", "31"):
         assert np.array_equal(frames[most][0].view(np.uint32), frames["1"][0].view(np.uint32)), most
         assert np.array_equal(frames[most][1], frames["1"][1])
         assert frames[most][2]["rays"] == frames["1"][2]["rays"]
     assert (frames["1"][0][:, 3] == spp).all()
-    monkeypatch.setenv("RTGI_HIP_FRAME_GROUP", "16")
+    monkeypatch.setenv("RTGI_HIP_FRAME_GROUP", "31")
     two = _renderer(s, devices=(0, 0)).render(sharding="samples", **kw)  # each part groups its own samples
     assert np.allclose(two[0][:, 0:3], frames["1"][0][:, 0:3], rtol=2e-6, atol=1e-7)
 
